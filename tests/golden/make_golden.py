@@ -1,0 +1,291 @@
+"""Generate the golden vectors under tests/golden/ from the reference itself.
+
+Runs ONLY in the build container, where /root/reference is mounted:
+
+    PYTHONDONTWRITEBYTECODE=1 python tests/golden/make_golden.py
+
+It imports the reference package (HyQD/quantum-systems v0.2.6), drives its own
+``BasisSet`` / ``QuantumSystem`` API on small seeded inputs and stores inputs
+and outputs as ``.npz``.  The fixtures are data (arrays); no reference source
+is written anywhere.
+
+The reference imports ``numba`` at package import time for two trivial helper
+functions that are not on the transform path (system_helper.py:4-11) and for
+its quantum-dot generators.  numba is not installed here, so an identity
+``njit`` decorator is registered below for the duration of this script; every
+array produced below comes from plain NumPy code in the reference.
+"""
+
+import os
+import sys
+import types
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def _import_reference():
+    nb = types.ModuleType("numba")
+
+    def passthrough(*args, **kwargs):
+        if len(args) == 1 and callable(args[0]) and not kwargs:
+            return args[0]
+        return lambda fn: fn
+
+    nb.njit = passthrough
+    nb.jit = passthrough
+    nb.prange = range
+    sys.modules.setdefault("numba", nb)
+    sys.path.insert(0, "/root/reference")
+    import quantum_systems
+
+    return quantum_systems
+
+
+qs = _import_reference()
+BasisSet = qs.BasisSet
+
+
+def save(name, **arrays):
+    path = os.path.join(HERE, name + ".npz")
+    np.savez_compressed(path, **arrays)
+    print(f"{name}: {os.path.getsize(path) / 1e3:.1f} kB")
+
+
+def crand(rng, *shape):
+    return rng.random(shape) + 1j * rng.random(shape)
+
+
+def case_transforms():
+    rng = np.random.default_rng(20241101)
+    # complex, square, non-unitary C (as tests/test_helper.py:38-69)
+    l = 6
+    u = crand(rng, l, l, l, l)
+    h = crand(rng, l, l)
+    C = crand(rng, l, l)
+    save(
+        "transform_c128_square",
+        u=u, h=h, C=C,
+        u_out=BasisSet.transform_two_body_elements(u, C, np),
+        h_out=BasisSet.transform_one_body_elements(h, C, np),
+    )
+    # complex, rectangular L=6 -> M=9, explicit C_tilde != C^dagger
+    C = crand(rng, l, 9)
+    Ct = crand(rng, 9, l)
+    save(
+        "transform_c128_rect_ctilde",
+        u=u, h=h, C=C, C_tilde=Ct,
+        u_out=BasisSet.transform_two_body_elements(u, C, np, C_tilde=Ct),
+        h_out=BasisSet.transform_one_body_elements(h, C, np, C_tilde=Ct),
+    )
+    # complex, rectangular shrinking L=6 -> M=4, default C_tilde
+    C = crand(rng, l, 4)
+    save(
+        "transform_c128_shrink",
+        u=u, h=h, C=C,
+        u_out=BasisSet.transform_two_body_elements(u, C, np),
+        h_out=BasisSet.transform_one_body_elements(h, C, np),
+    )
+    # real fp64, orthogonal C, odd l (unaligned rows)
+    l = 7
+    u = rng.standard_normal((l, l, l, l))
+    u = 0.5 * (u + u.transpose(1, 0, 3, 2))
+    h = rng.standard_normal((l, l))
+    C, _ = np.linalg.qr(rng.standard_normal((l, l)))
+    save(
+        "transform_f64_orthogonal",
+        u=u, h=h, C=C,
+        u_out=BasisSet.transform_two_body_elements(u, C, np),
+        h_out=BasisSet.transform_one_body_elements(h, C, np),
+    )
+    # real fp64 rectangular 7 -> 10
+    C = rng.standard_normal((l, 10))
+    save(
+        "transform_f64_rect",
+        u=u, h=h, C=C,
+        u_out=BasisSet.transform_two_body_elements(u, C, np),
+        h_out=BasisSet.transform_one_body_elements(h, C, np),
+    )
+    # mixed: real u, complex C (NumPy promotes to complex128)
+    C = crand(rng, l, l)
+    save(
+        "transform_mixed_real_u_complex_C",
+        u=u, h=h, C=C,
+        u_out=BasisSet.transform_two_body_elements(u, C, np),
+        h_out=BasisSet.transform_one_body_elements(h, C, np),
+    )
+    # spf transforms (basis_set.py:321-327)
+    spf = crand(rng, l, 5, 3)
+    bra = crand(rng, l, 5, 3)
+    Ct = crand(rng, l, l)
+    save(
+        "transform_spf",
+        spf=spf, bra_spf=bra, C=C, C_tilde=Ct,
+        spf_out=BasisSet.transform_spf(spf, C, np),
+        bra_out=BasisSet.transform_bra_spf(bra, Ct, np),
+    )
+
+
+def case_spin_statics():
+    rng = np.random.default_rng(7)
+    l = 5
+    u = rng.standard_normal((l, l, l, l))  # negative entries -> signed zeros
+    h = rng.standard_normal((l, l))
+    spf = crand(rng, l, 4)
+    us = BasisSet.add_spin_two_body(u, np)
+    save(
+        "spin_statics_f64",
+        u=u, h=h, spf=spf,
+        h_spin=BasisSet.add_spin_one_body(h, np),
+        u_spin=us,
+        u_spin_as=BasisSet.anti_symmetrize_u(us),
+        u_as=BasisSet.anti_symmetrize_u(u),
+        spf_spin=BasisSet.add_spin_spf(spf, np),
+    )
+    uc = crand(rng, l, l, l, l) - (0.5 + 0.5j)
+    usc = BasisSet.add_spin_two_body(uc, np)
+    save(
+        "spin_statics_c128",
+        u=uc,
+        u_spin=usc,
+        u_spin_as=BasisSet.anti_symmetrize_u(usc),
+        u_as=BasisSet.anti_symmetrize_u(uc),
+    )
+
+
+def _basis_fields(bs):
+    out = {}
+    for name in (
+        "h", "s", "u", "position", "momentum", "spf", "bra_spf",
+        "spin_x", "spin_y", "spin_z", "spin_2", "spin_2_tb",
+        "sigma_x", "sigma_y", "sigma_z",
+    ):
+        val = getattr(bs, name)
+        if val is not None:
+            out[name] = np.asarray(val)
+    return out
+
+
+def case_random_basis_stream():
+    # pins the draw order of RandomBasisSet (random_basis.py:21-35)
+    np.random.seed(1234)
+    rbs = qs.RandomBasisSet(4, 3)
+    save(
+        "random_basis_seed1234_l4_dim3",
+        nuclear_repulsion_energy=np.float64(rbs.nuclear_repulsion_energy),
+        charge=np.int64(rbs.charge),
+        **_basis_fields(rbs),
+    )
+
+
+def case_config1():
+    # BASELINE.json configs[0]: RandomBasisSet(l=20, dim=2), n=2, unitary C
+    np.random.seed(2024)
+    rbs = qs.RandomBasisSet(20, 2)
+    spas = qs.SpatialOrbitalSystem(2, rbs)
+    A = qs.RandomBasisSet.get_random_elements((20, 20), np)
+    C, _ = np.linalg.qr(A)
+    u_in_sample = spas.u[::3, 1::4, 2::5, ::2].copy()
+    spas.change_basis(C)
+    save(
+        "config1_l20_change_basis",
+        seed=np.int64(2024), C=C,
+        u_in_sample=u_in_sample,
+        n=np.int64(spas.n), l=np.int64(spas.l),
+        h=spas.h, s=spas.s, u=spas.u, position=spas.position,
+    )
+    # then the spin doubling of the transformed system: l=40, sampled
+    gos = spas.construct_general_orbital_system()
+    idx = np.random.default_rng(5).integers(0, 40, size=(4096, 4))
+    p, q, r, s = idx.T
+    save(
+        "config1_l20_gos_sampled",
+        idx=idx,
+        u_samples=gos.u[p, q, r, s],
+        spin_2_tb_samples=gos.spin_2_tb[p, q, r, s],
+        u_fro=np.float64(np.linalg.norm(gos.u)),
+        spin_2_tb_fro=np.float64(np.linalg.norm(gos.spin_2_tb)),
+        u_slab_p3=gos.u[3, :8],
+        h=gos.h, s=gos.s, spin_x=gos.spin_x, spin_y=gos.spin_y,
+        spin_z=gos.spin_z, spin_2=gos.spin_2, position=gos.position,
+        n=np.int64(gos.n), l=np.int64(gos.l),
+    )
+
+
+def case_gos_small():
+    # SpatialOrbitalSystem -> GeneralOrbitalSystem, full tensors, l=5 -> 10,
+    # then a rectangular change_basis on the spin basis (10 -> 8), which
+    # transforms u AND spin_2_tb (basis_set.py:374-382) and leaves the spin
+    # one-body operators untouched (:368-372).
+    np.random.seed(99)
+    rbs = qs.RandomBasisSet(5, 2)
+    spas = qs.SpatialOrbitalSystem(4, rbs)
+    spatial = _basis_fields(rbs)
+    gos = spas.construct_general_orbital_system()
+    doubled = _basis_fields(gos._basis_set)
+    C = qs.RandomBasisSet.get_random_elements((10, 8), np)
+    gos.change_basis(C)
+    after = _basis_fields(gos._basis_set)
+    save(
+        "gos_l5_default_spinors",
+        C=C,
+        **{"in_" + k: v for k, v in spatial.items()},
+        **{"gos_" + k: v for k, v in doubled.items()},
+        **{"cb_" + k: v for k, v in after.items()},
+        n_gos=np.int64(gos.n), l_after=np.int64(gos.l),
+    )
+    # custom spinor basis, no anti-symmetrisation, real-valued input with spf
+    rng = np.random.default_rng(3)
+    l = 4
+    bs = qs.BasisSet(l, dim=1, np=np)
+    bs.h = rng.standard_normal((l, l))
+    bs.s = np.eye(l) + 0.1 * rng.standard_normal((l, l))
+    bs.s = 0.5 * (bs.s + bs.s.T)
+    bs.u = rng.standard_normal((l, l, l, l))
+    bs.position = rng.standard_normal((1, l, l))
+    bs.momentum = rng.standard_normal((1, l, l))
+    bs.spf = crand(rng, l, 6)
+    spatial = _basis_fields(bs)
+    a = np.array([1, 1j]) / np.sqrt(2)
+    b = np.array([1, -1j]) / np.sqrt(2)
+    bs.change_to_general_orbital_basis(a=a, b=b, anti_symmetrize=False)
+    doubled = _basis_fields(bs)
+    save(
+        "gos_l4_custom_spinors_no_as",
+        a=a, b=b,
+        **{"in_" + k: v for k, v in spatial.items()},
+        **{"gos_" + k: v for k, v in doubled.items()},
+    )
+
+
+def case_change_basis_with_spf():
+    rng = np.random.default_rng(11)
+    l, m = 5, 7
+    bs = qs.BasisSet(l, dim=2, np=np)
+    bs.h = crand(rng, l, l)
+    bs.s = crand(rng, l, l)
+    bs.u = crand(rng, l, l, l, l)
+    bs.position = crand(rng, 2, l, l)
+    bs.momentum = crand(rng, 2, l, l)
+    bs.spf = crand(rng, l, 4, 3)
+    before = _basis_fields(bs)
+    C = crand(rng, l, m)
+    Ct = crand(rng, m, l)
+    bs.change_basis(C, C_tilde=Ct)
+    after = _basis_fields(bs)
+    save(
+        "change_basis_l5_to_7_spf_ctilde",
+        C=C, C_tilde=Ct,
+        **{"in_" + k: v for k, v in before.items()},
+        **{"out_" + k: v for k, v in after.items()},
+    )
+
+
+if __name__ == "__main__":
+    case_transforms()
+    case_spin_statics()
+    case_random_basis_stream()
+    case_config1()
+    case_gos_small()
+    case_change_basis_with_spf()
