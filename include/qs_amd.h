@@ -1,0 +1,182 @@
+/*
+ * qs_amd.h -- C ABI of the MI355X (gfx950) integral basis-transformation path.
+ *
+ * The reference (HyQD/quantum-systems v0.2.6) is pure Python and has no FFI:
+ * its seam is the injected array module (`np=` / `change_module`,
+ * quantum_systems/basis_set.py:32-38, :268-296).  The entry points below are
+ * what a binding for that seam calls in place of the NumPy calls on the hot
+ * path; each one names the reference call it replaces.  `INTEGRATION.md` shows
+ * the ctypes stub a maintainer of the reference would add.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer (hipMalloc / torch CUDA tensor
+ *     storage), 8-byte aligned (16 for complex), row-major, contiguous;
+ *   - complex128 is interleaved (re, im) doubles, as NumPy / torch store it;
+ *   - conjugation is resolved by the caller (`Ct` is passed explicitly);
+ *   - `stream` is a hipStream_t passed as void*; all work is enqueued on it
+ *     and the call returns without synchronising;
+ *   - the library allocates nothing: outputs and workspace are the caller's;
+ *   - return value: QS_OK (0) or a negative QS_ERR_* code, never throws.
+ *
+ * dtype codes: QS_F64 = real fp64, QS_C128 = complex128.
+ */
+#ifndef QS_AMD_H
+#define QS_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define QS_ABI_VERSION 1
+
+enum {
+    QS_OK = 0,
+    QS_ERR_BAD_EXTENT = -1,   /* non-positive or overflowing dimension      */
+    QS_ERR_NULL_POINTER = -2, /* required pointer is NULL                    */
+    QS_ERR_MISALIGNED = -3,   /* pointer not aligned to its element size     */
+    QS_ERR_WORKSPACE = -4,    /* workspace smaller than qs_*_workspace says  */
+    QS_ERR_HIP = -5,          /* a HIP runtime call or kernel launch failed  */
+    QS_ERR_BAD_DTYPE = -6,    /* dtype code not QS_F64 / QS_C128             */
+    QS_ERR_ALIAS = -7         /* output aliases an input where not allowed   */
+};
+
+enum { QS_F64 = 0, QS_C128 = 1 };
+
+/* ABI version of the loaded library (QS_ABI_VERSION it was built with). */
+int qs_abi_version(void);
+
+/* Text for a QS_ERR_* code (static storage). */
+const char* qs_error_string(int code);
+
+/* Last HIP error string recorded by this thread's most recent QS_ERR_HIP. */
+const char* qs_last_hip_error(void);
+
+/*
+ * Row-major (batched) matrix product  out[b] = A[b] . B[b]
+ *   A[b] : (m, k), leading dimension lda, batch stride stride_a (0 = shared)
+ *   B[b] : (k, n), leading dimension ldb, batch stride stride_b (0 = shared)
+ *   out[b]: (m, n), leading dimension ldc, batch stride stride_c
+ * Strides and leading dimensions are in ELEMENTS of the dtype.
+ * Replaces np.dot / np.tensordot over one index:
+ *   transform_spf / transform_bra_spf   basis_set.py:321-327
+ *   transform_one_body_elements         basis_set.py:329-334
+ * and is the building block of qs_transform_two_body.
+ */
+int qs_matmul(int dtype, const void* A, const void* B, void* out,
+              int64_t m, int64_t n, int64_t k,
+              int64_t lda, int64_t ldb, int64_t ldc,
+              int64_t batch, int64_t stride_a, int64_t stride_b,
+              int64_t stride_c, void* stream);
+
+/*
+ * Bytes of workspace qs_transform_two_body needs for u:(L,L,L,L) -> (M,M,M,M).
+ * Returns a negative QS_ERR_* on bad extents.
+ */
+int64_t qs_transform_two_body_workspace(int dtype, int64_t L, int64_t M);
+
+/*
+ * Four-index transform
+ *   out[p,q,r,s] = sum_abcd Ct[p,a] Ct[q,b] u[a,b,c,d] C[c,r] C[d,s]
+ * evaluated as the reference does, one index at a time in the order d, c, b, a.
+ *   u   : (L,L,L,L)   C : (L,M)   Ct : (M,L)   out : (M,M,M,M)
+ * `u` is not modified; `out` must not alias `u` or the workspace.
+ * Replaces BasisSet.transform_two_body_elements, basis_set.py:336-350.
+ */
+int qs_transform_two_body(int dtype, const void* u, const void* C,
+                          const void* Ct, void* out, void* work,
+                          int64_t work_bytes, int64_t L, int64_t M,
+                          void* stream);
+
+/*
+ * Same transform restricted to rows [a_lo, a_hi) of the leading index of `u`
+ * for the contractions over d, c, b only:
+ *   v[a,q,r,s] = sum_bcd Ct[q,b] u[a,b,c,d] C[c,r] C[d,s],  a in [a_lo,a_hi)
+ *   u_slab : (a_hi-a_lo, L, L, L)     v_slab : (a_hi-a_lo, M, M, M)
+ * The slab-local half of the sharded transform; the contraction
+ * over `a` is a plain qs_matmul on the exchanged slabs.
+ */
+int64_t qs_transform_two_body_partial_workspace(int dtype, int64_t L, int64_t M,
+                                                int64_t rows);
+int qs_transform_two_body_partial(int dtype, const void* u_slab, const void* C,
+                                  const void* Ct, void* v_slab, void* work,
+                                  int64_t work_bytes, int64_t L, int64_t M,
+                                  int64_t rows, void* stream);
+
+/*
+ * One-body transform of a stack of matrices:  out[i] = Ct . (h[i] . C)
+ *   h : (nmat, L, L)   out : (nmat, M, M)   work : nmat*L*M elements
+ * Replaces BasisSet.transform_one_body_elements, basis_set.py:329-334, as
+ * applied to h, s, position[i], momentum[i] (:358-406).
+ */
+int qs_transform_one_body(int dtype, const void* h, const void* C,
+                          const void* Ct, void* out, void* work,
+                          int64_t work_bytes, int64_t nmat, int64_t L,
+                          int64_t M, void* stream);
+
+/*
+ * Anti-symmetrisation  out[p,q,r,s] = u[p,q,r,s] - u[p,q,s,r]
+ *   u, out : (npq, l, l) with npq = number of leading (p,q) pairs handled
+ *            (l*l for a full tensor, fewer for a p-slab).
+ * `out` may equal `u` (in place).  Exact (one subtraction per element).
+ * Replaces BasisSet.anti_symmetrize_u, basis_set.py:776-778.
+ */
+int qs_antisymmetrize(int dtype, const void* u, void* out, int64_t npq,
+                      int64_t l, void* stream);
+
+/*
+ * Spin doubling of the two-body tensor, optionally fused with the
+ * anti-symmetrisation and the cast to complex128, for spatial rows
+ * p in [p_lo, p_hi):
+ *   out[2p+s1, 2q+s2, 2r+s3, 2s+s4] =
+ *        d(s1,s3) d(s2,s4) u[p,q,r,s]  - antisym * d(s1,s4) d(s2,s3) u[p,q,s,r]
+ *   u   : (l,l,l,l) of in_dtype (full tensor, indexed by absolute p)
+ *   out : (2*(p_hi-p_lo), 2l, 2l, 2l) of out_dtype (slab, first row = 2*p_lo)
+ * in_dtype QS_F64 may be combined with out_dtype QS_C128 (imaginary part 0).
+ * Replaces add_spin_two_body (basis_set.py:772-774) + anti_symmetrize_u
+ * (:776-778) + cast_to_complex (:298-319) inside
+ * change_to_general_orbital_basis (:530-636).
+ */
+int qs_spin_expand_two_body(int in_dtype, int out_dtype, const void* u,
+                            void* out, int64_t l, int64_t p_lo, int64_t p_hi,
+                            int antisymmetrize, void* stream);
+
+/*
+ * kron(h, I2) for a stack of matrices: out[i, 2p+s, 2q+t] = d(s,t) h[i,p,q]
+ *   h : (nmat, l, l) in_dtype     out : (nmat, 2l, 2l) out_dtype
+ * Replaces BasisSet.add_spin_one_body, basis_set.py:768-770.
+ */
+int qs_add_spin_one_body(int in_dtype, int out_dtype, const void* h, void* out,
+                         int64_t nmat, int64_t l, void* stream);
+
+/*
+ * Two-body part of S^2:
+ *   out[p,q,r,s] = sum_i S_i[p,r] S_i[q,s]  - antisym * S_i[p,s] S_i[q,r]
+ *   S : (3, n, n) complex128 (spin_x, spin_y, spin_z), out : rows
+ *   p in [p_lo, p_hi) of the (n,n,n,n) complex128 tensor.
+ * Replaces the einsum("pr,qs->pqrs") accumulation of
+ * setup_spin_squared_operator, basis_set.py:745-747 (+ :525-526).
+ */
+int qs_spin_squared_two_body(const void* S, void* out, int64_t n, int64_t p_lo,
+                             int64_t p_hi, int antisymmetrize, void* stream);
+
+/*
+ * Auxiliary entry points (no reference counterpart).
+ *   qs_tuning_set: override a kernel choice for tuning runs; keys
+ *     "gemm_f64_cfg", "gemm_c128_cfg" (0 = automatic).
+ *   qs_probe_mfma_f64: register-resident fp64 MFMA loop, `blocks` workgroups
+ *     of 4 waves, each wave issuing iters*8 v_mfma_f64_16x16x4_f64
+ *     (flops = blocks*4*iters*8*2048); `sink` is an 8-byte device scratch.
+ *   qs_probe_stream_copy: 16-byte-per-lane device copy (moves 2*bytes).
+ * bench.py uses the probes to print measured ceilings beside datasheet ones.
+ */
+int qs_tuning_set(const char* key, int64_t value);
+int qs_probe_mfma_f64(void* sink, int64_t blocks, int64_t iters, void* stream);
+int qs_probe_stream_copy(const void* src, void* dst, int64_t bytes, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* QS_AMD_H */

@@ -1,0 +1,219 @@
+// extern "C" surface of libqs_amd.so (include/qs_amd.h): argument checking,
+// workspace carving and the contraction schedule.  No kernels live here.
+//
+// contraction -> GEMM map for  out = Ct Ct u C C  (basis_set.py:341-348), all
+// operands row-major, L = old size, M = new size:
+//   d:  T1[(abc), s]   = sum_d u[(abc), d]  C[d, s]        m=rows*L^2 n=M   k=L
+//   c:  T2[ab][r, s]   = sum_c CT[r, c]     T1[ab][c, s]   batch rows*L, m=n=M, k=L
+//   b:  T3[a][q, (rs)] = sum_b Ct[q, b]     T2[a][b, (rs)] batch rows,   m=M n=M^2 k=L
+//   a:  out[p, (qrs)]  = sum_a Ct[p, a]     T3[a, (qrs)]   m=M n=M^3 k=L
+// CT = C^T is materialised once (L*M elements) so that every product is the
+// same row-major kernel with the tensor streamed along its contiguous axis.
+
+#include <string.h>
+
+#include "qs_common.h"
+
+namespace qs {
+
+static thread_local char g_hip_err[256] = "";
+
+void note_hip_error(hipError_t e, const char* what) {
+    snprintf(g_hip_err, sizeof(g_hip_err), "%s: %s", what, hipGetErrorString(e));
+}
+
+static int gemm(int dtype, const void* A, const void* B, void* C, int64_t m, int64_t n, int64_t k,
+                int64_t lda, int64_t ldb, int64_t ldc, int64_t batch, int64_t sa, int64_t sb,
+                int64_t sc, hipStream_t s) {
+    if (dtype == QS_F64)
+        return gemm_f64((const double*)A, (const double*)B, (double*)C, m, n, k, lda, ldb, ldc, batch,
+                        sa, sb, sc, s);
+    return gemm_c128((const double*)A, (const double*)B, (double*)C, m, n, k, lda, ldb, ldc, batch,
+                     sa, sb, sc, s);
+}
+
+static inline int64_t even_up(int64_t x) { return (x + 1) & ~int64_t(1); }
+
+// Extents for which every product keeps its n and grid inside 32 bits.
+static bool extents_ok(int64_t L, int64_t M) {
+    if (L <= 0 || M <= 0) return false;
+    if (L > 4096 || M > 1024) return false;   // M^3 < 2^31 needs M <= 1290
+    return true;
+}
+
+static inline char* at(void* base, int64_t elems, size_t es) { return (char*)base + (size_t)elems * es; }
+
+// contractions d, c, b on `rows` leading-index rows
+static int contract_dcb(int dtype, const void* u, const void* C, const void* CT, const void* Ct,
+                        void* T1, void* T2, void* T3, int64_t rows, int64_t L, int64_t M,
+                        hipStream_t s) {
+    int rc = gemm(dtype, u, C, T1, rows * L * L, M, L, L, M, M, 1, 0, 0, 0, s);
+    if (rc) return rc;
+    rc = gemm(dtype, CT, T1, T2, M, M, L, L, M, M, rows * L, 0, L * M, M * M, s);
+    if (rc) return rc;
+    return gemm(dtype, Ct, T2, T3, M, M * M, L, L, M * M, M * M, rows, 0, L * M * M, M * M * M, s);
+}
+
+}  // namespace qs
+
+using namespace qs;
+
+extern "C" {
+
+int qs_abi_version(void) { return QS_ABI_VERSION; }
+
+const char* qs_error_string(int code) {
+    switch (code) {
+        case QS_OK: return "ok";
+        case QS_ERR_BAD_EXTENT: return "bad extent (non-positive, inconsistent or too large)";
+        case QS_ERR_NULL_POINTER: return "null pointer";
+        case QS_ERR_MISALIGNED: return "pointer not aligned to its element size";
+        case QS_ERR_WORKSPACE: return "workspace too small";
+        case QS_ERR_HIP: return "HIP runtime error";
+        case QS_ERR_BAD_DTYPE: return "unsupported dtype code";
+        case QS_ERR_ALIAS: return "output aliases an input";
+        default: return "unknown error code";
+    }
+}
+
+const char* qs_last_hip_error(void) { return g_hip_err; }
+
+int qs_tuning_set(const char* key, int64_t value) {
+    if (!key) return QS_ERR_NULL_POINTER;
+    if (!strcmp(key, "gemm_f64_cfg")) { g_gemm_f64_cfg = (int)value; return QS_OK; }
+    if (!strcmp(key, "gemm_c128_cfg")) { g_gemm_c128_cfg = (int)value; return QS_OK; }
+    return QS_ERR_BAD_EXTENT;
+}
+
+int qs_matmul(int dtype, const void* A, const void* B, void* out, int64_t m, int64_t n, int64_t k,
+              int64_t lda, int64_t ldb, int64_t ldc, int64_t batch, int64_t stride_a,
+              int64_t stride_b, int64_t stride_c, void* stream) {
+    if (!dtype_ok(dtype)) return QS_ERR_BAD_DTYPE;
+    if (!A || !B || !out) return QS_ERR_NULL_POINTER;
+    const size_t es = elem_size(dtype);
+    if (!aligned(A, es) || !aligned(B, es) || !aligned(out, es)) return QS_ERR_MISALIGNED;
+    if (stride_a < 0 || stride_b < 0 || stride_c < 0) return QS_ERR_BAD_EXTENT;
+    return gemm(dtype, A, B, out, m, n, k, lda, ldb, ldc, batch, stride_a, stride_b, stride_c,
+                (hipStream_t)stream);
+}
+
+int64_t qs_transform_two_body_workspace(int dtype, int64_t L, int64_t M) {
+    if (!dtype_ok(dtype)) return QS_ERR_BAD_DTYPE;
+    if (!extents_ok(L, M)) return QS_ERR_BAD_EXTENT;
+    const int64_t wa = (L * L * L * M > L * M * M * M) ? L * L * L * M : L * M * M * M;
+    const int64_t wb = (M < L) ? L * L * M * M : 0;   // otherwise T2 lives in `out`
+    return (even_up(L * M) + wa + wb) * (int64_t)elem_size(dtype);
+}
+
+int qs_transform_two_body(int dtype, const void* u, const void* C, const void* Ct, void* out,
+                          void* work, int64_t work_bytes, int64_t L, int64_t M, void* stream) {
+    if (!dtype_ok(dtype)) return QS_ERR_BAD_DTYPE;
+    if (!extents_ok(L, M)) return QS_ERR_BAD_EXTENT;
+    if (!u || !C || !Ct || !out || !work) return QS_ERR_NULL_POINTER;
+    const size_t es = elem_size(dtype);
+    if (!aligned(u, es) || !aligned(C, es) || !aligned(Ct, es) || !aligned(out, es) ||
+        !aligned(work, 16))
+        return QS_ERR_MISALIGNED;
+    if (out == u || out == work) return QS_ERR_ALIAS;
+    if (work_bytes < qs_transform_two_body_workspace(dtype, L, M)) return QS_ERR_WORKSPACE;
+    hipStream_t s = (hipStream_t)stream;
+
+    void* CT = work;
+    void* WA = at(work, even_up(L * M), es);
+    const int64_t wa = (L * L * L * M > L * M * M * M) ? L * L * L * M : L * M * M * M;
+    void* WB = (M < L) ? at(WA, wa, es) : out;
+
+    int rc = transpose_small(dtype, C, CT, L, M, s);
+    if (rc) return rc;
+    rc = contract_dcb(dtype, u, C, CT, Ct, /*T1*/ WA, /*T2*/ WB, /*T3*/ WA, L, L, M, s);
+    if (rc) return rc;
+    return gemm(dtype, Ct, WA, out, M, M * M * M, L, L, M * M * M, M * M * M, 1, 0, 0, 0, s);
+}
+
+int64_t qs_transform_two_body_partial_workspace(int dtype, int64_t L, int64_t M, int64_t rows) {
+    if (!dtype_ok(dtype)) return QS_ERR_BAD_DTYPE;
+    if (!extents_ok(L, M) || rows <= 0 || rows > L) return QS_ERR_BAD_EXTENT;
+    return (even_up(L * M) + rows * L * L * M + rows * L * M * M) * (int64_t)elem_size(dtype);
+}
+
+int qs_transform_two_body_partial(int dtype, const void* u_slab, const void* C, const void* Ct,
+                                  void* v_slab, void* work, int64_t work_bytes, int64_t L,
+                                  int64_t M, int64_t rows, void* stream) {
+    if (!dtype_ok(dtype)) return QS_ERR_BAD_DTYPE;
+    if (!extents_ok(L, M) || rows <= 0 || rows > L) return QS_ERR_BAD_EXTENT;
+    if (!u_slab || !C || !Ct || !v_slab || !work) return QS_ERR_NULL_POINTER;
+    const size_t es = elem_size(dtype);
+    if (!aligned(u_slab, es) || !aligned(C, es) || !aligned(Ct, es) || !aligned(v_slab, es) ||
+        !aligned(work, 16))
+        return QS_ERR_MISALIGNED;
+    if (v_slab == u_slab || v_slab == work) return QS_ERR_ALIAS;
+    if (work_bytes < qs_transform_two_body_partial_workspace(dtype, L, M, rows)) return QS_ERR_WORKSPACE;
+    hipStream_t s = (hipStream_t)stream;
+    void* CT = work;
+    void* T1 = at(work, even_up(L * M), es);
+    void* T2 = at(T1, rows * L * L * M, es);
+    int rc = transpose_small(dtype, C, CT, L, M, s);
+    if (rc) return rc;
+    return contract_dcb(dtype, u_slab, C, CT, Ct, T1, T2, v_slab, rows, L, M, s);
+}
+
+int qs_transform_one_body(int dtype, const void* h, const void* C, const void* Ct, void* out,
+                          void* work, int64_t work_bytes, int64_t nmat, int64_t L, int64_t M,
+                          void* stream) {
+    if (!dtype_ok(dtype)) return QS_ERR_BAD_DTYPE;
+    if (L <= 0 || M <= 0 || nmat <= 0 || L > 65536 || M > 65536) return QS_ERR_BAD_EXTENT;
+    if (!h || !C || !Ct || !out || !work) return QS_ERR_NULL_POINTER;
+    const size_t es = elem_size(dtype);
+    if (!aligned(h, es) || !aligned(C, es) || !aligned(Ct, es) || !aligned(out, es) || !aligned(work, 16))
+        return QS_ERR_MISALIGNED;
+    if (out == h || out == work) return QS_ERR_ALIAS;
+    if (work_bytes < nmat * L * M * (int64_t)es) return QS_ERR_WORKSPACE;
+    hipStream_t s = (hipStream_t)stream;
+    // T[(i,a), q] = sum_b h[i][a, b] C[b, q]
+    int rc = gemm(dtype, h, C, work, nmat * L, M, L, L, M, M, 1, 0, 0, 0, s);
+    if (rc) return rc;
+    // out[i][p, q] = sum_a Ct[p, a] T[i][a, q]
+    return gemm(dtype, Ct, work, out, M, M, L, L, M, M, nmat, 0, L * M, M * M, s);
+}
+
+int qs_antisymmetrize(int dtype, const void* u, void* out, int64_t npq, int64_t l, void* stream) {
+    if (!dtype_ok(dtype)) return QS_ERR_BAD_DTYPE;
+    if (npq <= 0 || l <= 0 || l > 65536) return QS_ERR_BAD_EXTENT;
+    if (!u || !out) return QS_ERR_NULL_POINTER;
+    const size_t es = elem_size(dtype);
+    if (!aligned(u, es) || !aligned(out, es)) return QS_ERR_MISALIGNED;
+    return antisymmetrize(dtype, u, out, npq, l, (hipStream_t)stream);
+}
+
+int qs_spin_expand_two_body(int in_dtype, int out_dtype, const void* u, void* out, int64_t l,
+                            int64_t p_lo, int64_t p_hi, int antisymmetrize_flag, void* stream) {
+    if (!dtype_ok(in_dtype) || !dtype_ok(out_dtype)) return QS_ERR_BAD_DTYPE;
+    if (in_dtype == QS_C128 && out_dtype == QS_F64) return QS_ERR_BAD_DTYPE;
+    if (l <= 0 || l > 32768 || p_lo < 0 || p_hi > l || p_lo >= p_hi) return QS_ERR_BAD_EXTENT;
+    if (!u || !out) return QS_ERR_NULL_POINTER;
+    if (!aligned(u, elem_size(in_dtype)) || !aligned(out, elem_size(out_dtype))) return QS_ERR_MISALIGNED;
+    if (out == u) return QS_ERR_ALIAS;
+    return spin_expand(in_dtype, out_dtype, u, out, l, p_lo, p_hi, antisymmetrize_flag ? 1 : 0,
+                       (hipStream_t)stream);
+}
+
+int qs_add_spin_one_body(int in_dtype, int out_dtype, const void* h, void* out, int64_t nmat,
+                         int64_t l, void* stream) {
+    if (!dtype_ok(in_dtype) || !dtype_ok(out_dtype)) return QS_ERR_BAD_DTYPE;
+    if (in_dtype == QS_C128 && out_dtype == QS_F64) return QS_ERR_BAD_DTYPE;
+    if (l <= 0 || nmat <= 0 || l > (1 << 20)) return QS_ERR_BAD_EXTENT;
+    if (!h || !out) return QS_ERR_NULL_POINTER;
+    if (!aligned(h, elem_size(in_dtype)) || !aligned(out, elem_size(out_dtype))) return QS_ERR_MISALIGNED;
+    if (out == h) return QS_ERR_ALIAS;
+    return kron_eye2(in_dtype, out_dtype, h, out, nmat, l, (hipStream_t)stream);
+}
+
+int qs_spin_squared_two_body(const void* S, void* out, int64_t n, int64_t p_lo, int64_t p_hi,
+                             int antisymmetrize_flag, void* stream) {
+    if (n <= 0 || n > 65536 || p_lo < 0 || p_hi > n || p_lo >= p_hi) return QS_ERR_BAD_EXTENT;
+    if (!S || !out) return QS_ERR_NULL_POINTER;
+    if (!aligned(S, 16) || !aligned(out, 16)) return QS_ERR_MISALIGNED;
+    return spin2_two_body(S, out, n, p_lo, p_hi, antisymmetrize_flag ? 1 : 0, (hipStream_t)stream);
+}
+
+}  // extern "C"

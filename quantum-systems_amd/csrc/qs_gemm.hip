@@ -1,0 +1,341 @@
+// Batched row-major matrix product on the gfx950 fp64 matrix cores, real
+// fp64 and complex128 (interleaved re/im) in one kernel template.
+//
+//   C[b] (m x n) = A[b] (m x k) . B[b] (k x n)
+//
+// This is the one compute kernel of the four-index transform: each of the four
+// single-index contractions of quantum_systems/basis_set.py:341-348 is this
+// product with the rank-4 tensor viewed as a (batched) row-major matrix, so
+// every global access of the big tensor is a contiguous run along its last
+// axis (DESIGN.md "contraction -> GEMM map").
+//
+// Machine mapping (MI355X / CDNA4):
+//   * v_mfma_f64_16x16x4_f64: one wave owns a (16*TM) x (16*TN) block of C in
+//     TM*TN accumulators of 4 fp64 each (8 VGPRs); operand fragments are one
+//     fp64 per lane: A[i = lane&15][k = lane>>4], B[k = lane>>4][j = lane&15];
+//     result reg r of a lane holds C[(lane>>4) + 4r][lane&15].
+//   * complex128: re and im are split into two LDS planes while staging, the
+//     product is the plain 4-multiply form on four MFMAs per fragment pair
+//     (re += ar*br; re += (-ai)*bi; im += ar*bi; im += ai*br) -- no 3M trick,
+//     so rounding behaves like the reference's zgemm.
+//   * a workgroup of WM x WN waves computes a (16*TM*WM) x (16*TN*WN) tile; K
+//     is walked KT at a time through two LDS stages; the next stage is fetched
+//     global->registers before the current one feeds the MFMAs and is written
+//     to LDS after them (one barrier per K step).
+//   * LDS rows are padded so both fragment reads are conflict-free
+//     ds_read_b64 (A row stride KT+2 doubles, B row stride BN+16).
+//   * 4-wave workgroups run two per CU, so one workgroup's epilogue stores and
+//     prologue loads hide under the other's MFMAs.
+//   * blockIdx -> tile mapping hands every XCD a contiguous run of tiles and
+//     walks the tiles that share a panel of the streamed operand first, so the
+//     second reader of a panel hits that XCD's L2.
+//
+// fp64 MFMA issues one 16x16x4 (2048 flop) per 64 cycles per SIMD:
+// 256 CU x 4 SIMD x 32 flop/clk x 2.4 GHz = 78.6 TFLOP/s peak.
+
+#include <type_traits>
+
+#include "qs_common.h"
+
+namespace qs {
+
+typedef double f64x4 __attribute__((ext_vector_type(4)));
+typedef double f64x2 __attribute__((ext_vector_type(2)));
+
+enum { MODE_F64_SCALAR = 0, MODE_F64_VEC2 = 1, MODE_C128 = 2 };
+
+struct GemmArgs {
+    const double* A;
+    const double* B;
+    double* C;
+    int64_t lda, ldb, ldc;   // elements
+    int64_t sa, sb, sc;      // elements
+    int m, n, k;
+    int tiles_m, tiles_n;
+    int group_along_m;   // 1: tiles that share a B panel (same n-tile) are adjacent
+};
+
+// Work index of a workgroup: XCD x gets the x-th contiguous chunk of the work
+// list (bijective for every grid size); consecutive slots of one XCD are
+// consecutive work items.  Placement only affects speed, never results.
+__device__ __forceinline__ unsigned xcd_chunked_index(unsigned bid, unsigned nwg) {
+    const unsigned xcd = bid & 7u, slot = bid >> 3;
+    const unsigned q = nwg >> 3, r = nwg & 7u;
+    const unsigned base = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+    return base + slot;
+}
+
+template <int WM, int WN, int TM, int TN, int KT, int MODE>
+__global__ __launch_bounds__(64 * WM * WN, (WM * WN <= 4) ? 2 : 1)
+void gemm_kernel(const GemmArgs g) {
+    constexpr bool CX = (MODE == MODE_C128);
+    constexpr bool SCALAR = (MODE == MODE_F64_SCALAR);
+    constexpr int NP = CX ? 2 : 1;            // LDS planes (re, im)
+    constexpr int ES = CX ? 2 : 1;            // doubles per element
+    constexpr int NT = 64 * WM * WN;
+    constexpr int BM = 16 * TM * WM;
+    constexpr int BN = 16 * TN * WN;
+    constexpr int SA = KT + 2;                // (SA/2) odd -> 16 rows hit 16 distinct bank pairs
+    constexpr int SB = BN + 16;               // consecutive k rows land 16 bank pairs apart
+    static_assert(KT == 8 || KT == 16, "KT");
+    // staging: one item = 16 bytes (f64x2 or one complex) except scalar mode (8 bytes)
+    constexpr int IPR_A = SCALAR ? KT : (CX ? KT : KT / 2);   // items per A row
+    constexpr int IPR_B = SCALAR ? BN : (CX ? BN : BN / 2);   // items per B row
+    constexpr int NA = BM * IPR_A / NT;
+    constexpr int NB = KT * IPR_B / NT;
+    static_assert(NA * NT == BM * IPR_A && NA > 0, "A stage not divisible");
+    static_assert(NB * NT == KT * IPR_B && NB > 0, "B stage not divisible");
+    constexpr int A_STAGE = NP * BM * SA;     // doubles
+    constexpr int B_STAGE = NP * KT * SB;
+
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    double* As = smem;                        // [2][NP][BM][SA]
+    double* Bs = smem + 2 * A_STAGE;          // [2][NP][KT][SB]
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int wm = wave / WN, wn = wave % WN;
+
+    unsigned w = xcd_chunked_index(blockIdx.x, gridDim.x);
+    int mt, nt;
+    if (g.group_along_m) {
+        mt = w % g.tiles_m; w /= g.tiles_m;
+        nt = w % g.tiles_n; w /= g.tiles_n;
+    } else {
+        nt = w % g.tiles_n; w /= g.tiles_n;
+        mt = w % g.tiles_m; w /= g.tiles_m;
+    }
+    const int64_t b = w;
+    const int m0 = mt * BM, n0 = nt * BN;
+    const double* __restrict__ A = g.A + b * g.sa * ES;
+    const double* __restrict__ B = g.B + b * g.sb * ES;
+    double* __restrict__ C = g.C + b * g.sc * ES;
+    const int M = g.m, N = g.n, K = g.k;
+
+    typedef typename std::conditional<SCALAR, double, f64x2>::type item_t;
+    item_t ra[NA], rb[NB];
+
+    auto fetch = [&](int k0) {
+#pragma unroll
+        for (int i = 0; i < NA; ++i) {
+            const int c = tid + i * NT;
+            const int row = c / IPR_A;
+            const int kc = (c % IPR_A) * ((SCALAR || CX) ? 1 : 2);
+            const int gr = m0 + row, gk = k0 + kc;
+            const bool ok = gr < M && gk < K;
+            const double* p = A + ((int64_t)gr * g.lda + gk) * ES;
+            if constexpr (SCALAR) ra[i] = ok ? *p : 0.0;
+            else ra[i] = ok ? *reinterpret_cast<const f64x2*>(p) : f64x2{0.0, 0.0};
+        }
+#pragma unroll
+        for (int i = 0; i < NB; ++i) {
+            const int c = tid + i * NT;
+            const int row = c / IPR_B;
+            const int nc = (c % IPR_B) * ((SCALAR || CX) ? 1 : 2);
+            const int gk = k0 + row, gn = n0 + nc;
+            const bool ok = gk < K && gn < N;
+            const double* p = B + ((int64_t)gk * g.ldb + gn) * ES;
+            if constexpr (SCALAR) rb[i] = ok ? *p : 0.0;
+            else rb[i] = ok ? *reinterpret_cast<const f64x2*>(p) : f64x2{0.0, 0.0};
+        }
+    };
+
+    auto stash = [&](int buf) {
+        double* as = As + buf * A_STAGE;
+        double* bs = Bs + buf * B_STAGE;
+#pragma unroll
+        for (int i = 0; i < NA; ++i) {
+            const int c = tid + i * NT;
+            const int row = c / IPR_A;
+            const int kc = (c % IPR_A) * ((SCALAR || CX) ? 1 : 2);
+            double* d = as + row * SA + kc;
+            if constexpr (SCALAR) *d = ra[i];
+            else if constexpr (CX) { d[0] = ra[i][0]; d[BM * SA] = ra[i][1]; }
+            else *reinterpret_cast<f64x2*>(d) = ra[i];
+        }
+#pragma unroll
+        for (int i = 0; i < NB; ++i) {
+            const int c = tid + i * NT;
+            const int row = c / IPR_B;
+            const int nc = (c % IPR_B) * ((SCALAR || CX) ? 1 : 2);
+            double* d = bs + row * SB + nc;
+            if constexpr (SCALAR) *d = rb[i];
+            else if constexpr (CX) { d[0] = rb[i][0]; d[KT * SB] = rb[i][1]; }
+            else *reinterpret_cast<f64x2*>(d) = rb[i];
+        }
+    };
+
+    f64x4 acc[NP][TM][TN];
+#pragma unroll
+    for (int p = 0; p < NP; ++p)
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j) acc[p][i][j] = f64x4{0.0, 0.0, 0.0, 0.0};
+
+    const int nk = (K + KT - 1) / KT;
+    fetch(0);
+    stash(0);
+    __syncthreads();
+
+    const int a_off = (wm * 16 * TM + (lane & 15)) * SA + (lane >> 4);
+    const int b_off = (lane >> 4) * SB + wn * 16 * TN + (lane & 15);
+
+    for (int t = 0; t < nk; ++t) {
+        const int cur = t & 1;
+        if (t + 1 < nk) fetch((t + 1) * KT);
+        const double* as = As + cur * A_STAGE + a_off;
+        const double* bs = Bs + cur * B_STAGE + b_off;
+#pragma unroll
+        for (int kk = 0; kk < KT / 4; ++kk) {
+            double af[NP][TM], bf[NP][TN];
+#pragma unroll
+            for (int p = 0; p < NP; ++p) {
+#pragma unroll
+                for (int i = 0; i < TM; ++i) af[p][i] = as[p * BM * SA + i * 16 * SA + kk * 4];
+#pragma unroll
+                for (int j = 0; j < TN; ++j) bf[p][j] = bs[p * KT * SB + kk * 4 * SB + j * 16];
+            }
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    if constexpr (!CX) {
+                        acc[0][i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[0][i], bf[0][j], acc[0][i][j], 0, 0, 0);
+                    } else {
+                        acc[0][i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[0][i], bf[0][j], acc[0][i][j], 0, 0, 0);
+                        acc[1][i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[0][i], bf[1][j], acc[1][i][j], 0, 0, 0);
+                        acc[0][i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(-af[1][i], bf[1][j], acc[0][i][j], 0, 0, 0);
+                        acc[1][i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[1][i], bf[0][j], acc[1][i][j], 0, 0, 0);
+                    }
+                }
+            }
+        }
+        if (t + 1 < nk) stash(cur ^ 1);
+        __syncthreads();
+    }
+
+    // epilogue: reg r of a lane -> row (lane>>4) + 4r, col lane&15 of each 16x16 block
+    const int crow = m0 + wm * 16 * TM + (lane >> 4);
+    const int ccol = n0 + wn * 16 * TN + (lane & 15);
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int row = crow + i * 16 + 4 * r;
+            if (row < M) {
+                double* crow_ptr = C + (int64_t)row * g.ldc * ES;
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    const int col = ccol + j * 16;
+                    if (col < N) {
+                        if constexpr (CX)
+                            *reinterpret_cast<f64x2*>(crow_ptr + 2 * (int64_t)col) =
+                                f64x2{acc[0][i][j][r], acc[1][i][j][r]};
+                        else
+                            crow_ptr[col] = acc[0][i][j][r];
+                    }
+                }
+            }
+        }
+    }
+}
+
+template <int WM, int WN, int TM, int TN, int KT, int MODE>
+static int launch_one(GemmArgs g, int64_t batch, hipStream_t stream) {
+    constexpr int BM = 16 * TM * WM, BN = 16 * TN * WN;
+    constexpr int NP = MODE == MODE_C128 ? 2 : 1;
+    g.tiles_m = (int)cdiv(g.m, BM);
+    g.tiles_n = (int)cdiv(g.n, BN);
+    const int64_t nwg = (int64_t)g.tiles_m * g.tiles_n * batch;
+    if (nwg <= 0 || nwg >= (int64_t(1) << 31)) return QS_ERR_BAD_EXTENT;
+    const size_t lds = sizeof(double) * 2 * NP * (BM * (KT + 2) + KT * (BN + 16));
+    auto kern = gemm_kernel<WM, WN, TM, TN, KT, MODE>;
+    static bool lds_opt_in = false;   // per instantiation; a repeated call is harmless
+    if (lds > 64 * 1024 && !lds_opt_in) {
+        hipError_t e = hipFuncSetAttribute((const void*)kern,
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return hip_status(e, "hipFuncSetAttribute(gemm)");
+        lds_opt_in = true;
+    }
+    hipLaunchKernelGGL(kern, dim3((unsigned)nwg), dim3(64 * WM * WN), lds, stream, g);
+    return launch_status("gemm launch");
+}
+
+// Tile-shape overrides for tuning runs (qs_tuning_set); 0 = automatic choice.
+int g_gemm_f64_cfg = 0;
+int g_gemm_c128_cfg = 0;
+
+static bool fill_args(GemmArgs& g, const double* A, const double* B, double* C, int64_t m,
+                      int64_t n, int64_t k, int64_t lda, int64_t ldb, int64_t ldc, int64_t batch,
+                      int64_t sa, int64_t sb, int64_t sc) {
+    if (m <= 0 || n <= 0 || k <= 0 || batch <= 0) return false;
+    if (m > INT32_MAX || n > INT32_MAX || k > INT32_MAX) return false;
+    if (lda < k || ldb < n || ldc < n) return false;
+    g.A = A; g.B = B; g.C = C;
+    g.lda = lda; g.ldb = ldb; g.ldc = ldc;
+    g.sa = sa; g.sb = sb; g.sc = sc;
+    g.m = (int)m; g.n = (int)n; g.k = (int)k;
+    g.tiles_m = g.tiles_n = 0;
+    // Which operand is the stream that neighbouring tiles should share in L2:
+    // a shared (stride-0) A, or a short-and-wide product, streams B.
+    g.group_along_m = ((sa == 0 && batch > 1) || m < n) ? 1 : 0;
+    return true;
+}
+
+template <int MODE>
+static int dispatch_f64(int cfg, const GemmArgs& g, int64_t batch, hipStream_t s) {
+    switch (cfg) {
+        case 1: return launch_one<2, 2, 4, 4, 16, MODE>(g, batch, s);   // 128 x 128, 2 WG/CU
+        case 2: return launch_one<4, 1, 4, 4, 16, MODE>(g, batch, s);   // 256 x  64
+        case 3: return launch_one<1, 4, 4, 4, 16, MODE>(g, batch, s);   //  64 x 256
+        case 4: return launch_one<1, 1, 4, 4, 16, MODE>(g, batch, s);   //  64 x  64, 1 wave
+        case 5: return launch_one<2, 2, 2, 2, 16, MODE>(g, batch, s);   //  64 x  64, 4 waves
+        case 6: return launch_one<4, 2, 4, 4, 16, MODE>(g, batch, s);   // 256 x 128, 8 waves
+        case 7: return launch_one<2, 4, 4, 4, 16, MODE>(g, batch, s);   // 128 x 256, 8 waves
+        default: return QS_ERR_BAD_EXTENT;
+    }
+}
+
+int gemm_f64(const double* A, const double* B, double* C, int64_t m, int64_t n, int64_t k,
+             int64_t lda, int64_t ldb, int64_t ldc, int64_t batch, int64_t sa, int64_t sb,
+             int64_t sc, hipStream_t stream) {
+    GemmArgs g;
+    if (!fill_args(g, A, B, C, m, n, k, lda, ldb, ldc, batch, sa, sb, sc)) return QS_ERR_BAD_EXTENT;
+    // 16-byte loads need even extents/strides and 16-byte aligned bases.
+    const bool vec = aligned(A, 16) && aligned(B, 16) && !(lda & 1) && !(ldb & 1) && !(k & 1) &&
+                     !(n & 1) && !(sa & 1) && !(sb & 1);
+    int cfg = g_gemm_f64_cfg;
+    if (cfg == 0) {
+        if (m <= 64 && n <= 64) cfg = (batch >= 2048) ? 4 : 5;
+        else if (n <= 64) cfg = 2;
+        else if (m <= 64) cfg = 3;
+        else cfg = 1;
+    }
+    return vec ? dispatch_f64<MODE_F64_VEC2>(cfg, g, batch, stream)
+               : dispatch_f64<MODE_F64_SCALAR>(cfg, g, batch, stream);
+}
+
+int gemm_c128(const double* A, const double* B, double* C, int64_t m, int64_t n, int64_t k,
+              int64_t lda, int64_t ldb, int64_t ldc, int64_t batch, int64_t sa, int64_t sb,
+              int64_t sc, hipStream_t stream) {
+    GemmArgs g;
+    if (!fill_args(g, A, B, C, m, n, k, lda, ldb, ldc, batch, sa, sb, sc)) return QS_ERR_BAD_EXTENT;
+    int cfg = g_gemm_c128_cfg;
+    if (cfg == 0) {
+        if (m <= 32 && n <= 32) cfg = 4;
+        else if (m >= n) cfg = 2;
+        else cfg = 1;
+    }
+    switch (cfg) {
+        case 1: return launch_one<2, 2, 2, 4, 8, MODE_C128>(g, batch, stream);   //  64 x 128
+        case 2: return launch_one<2, 2, 4, 2, 8, MODE_C128>(g, batch, stream);   // 128 x  64
+        case 3: return launch_one<4, 1, 2, 4, 8, MODE_C128>(g, batch, stream);   // 128 x  64 (tall waves)
+        case 4: return launch_one<2, 2, 1, 1, 8, MODE_C128>(g, batch, stream);   //  32 x  32
+        case 5: return launch_one<1, 4, 2, 4, 8, MODE_C128>(g, batch, stream);   //  32 x 256
+        default: return QS_ERR_BAD_EXTENT;
+    }
+}
+
+}  // namespace qs

@@ -1,0 +1,295 @@
+"""Typed Python front of the C ABI: torch tensors in, torch tensors out.
+
+PyTorch is used here for what it is good at on ROCm -- owning device memory
+and the current HIP stream.  Every function hands raw device pointers to
+``libqs_amd.so``; none of them computes anything with torch ops, and none has a
+CPU path: a tensor that is not on a ``cuda`` device is an error.
+"""
+
+import torch
+
+from . import _lib
+from ._lib import QS_C128, QS_F64, check
+
+_F64 = torch.float64
+_C128 = torch.complex128
+
+
+def dtype_code(dtype):
+    if dtype == _F64:
+        return QS_F64
+    if dtype == _C128:
+        return QS_C128
+    raise TypeError(f"only float64 and complex128 are supported, got {dtype}")
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _dev(t, dtype=None):
+    """Contiguous, conjugation-resolved device tensor of the wanted dtype."""
+    if not isinstance(t, torch.Tensor):
+        raise TypeError("expected a torch.Tensor")
+    if not t.is_cuda:
+        raise RuntimeError(
+            "the transform path runs on the GPU only: move the array to the "
+            "device module first (change_module)"
+        )
+    if dtype is not None and t.dtype != dtype:
+        t = t.to(dtype)
+    return t.resolve_conj().contiguous()
+
+
+def result_dtype(*tensors):
+    """NumPy-style promotion restricted to {float64, complex128}."""
+    out = _F64
+    for t in tensors:
+        if t.dtype in (torch.complex64, _C128):
+            out = _C128
+        elif t.dtype not in (_F64, torch.float32, torch.int64, torch.int32):
+            raise TypeError(f"unsupported dtype {t.dtype}")
+    return out
+
+
+def default_bra(C):
+    """``C.conj().T`` materialised (basis_set.py:331-332, 338-339)."""
+    return C.conj().transpose(0, 1).resolve_conj().contiguous()
+
+
+class Workspace:
+    """Grow-only device scratch shared by the transforms of one process.
+
+    The C ABI never allocates; this keeps one buffer alive between calls so a
+    time loop calling the transform every step does not hit the allocator."""
+
+    def __init__(self):
+        self._buf = None
+
+    def get(self, nbytes, device):
+        if (
+            self._buf is None
+            or self._buf.numel() < nbytes
+            or self._buf.device != device
+        ):
+            self._buf = None  # release before growing
+            self._buf = torch.empty(int(nbytes), dtype=torch.uint8, device=device)
+        return self._buf
+
+    def release(self):
+        self._buf = None
+
+
+workspace = Workspace()
+
+
+def matmul(A, B, out=None):
+    """Row-major ``A @ B`` for 2-D operands (or a shared 2-D ``A`` against a
+    batch ``B`` of shape (batch, k, n))."""
+    lib = _lib.load()
+    dt = result_dtype(A, B)
+    A = _dev(A, dt)
+    B = _dev(B, dt)
+    if A.dim() != 2:
+        raise ValueError("A must be 2-D")
+    m, k = A.shape
+    if B.dim() == 2:
+        batch, (kb, n) = 1, B.shape
+        oshape = (m, n)
+    elif B.dim() == 3:
+        batch, kb, n = B.shape
+        oshape = (batch, m, n)
+    else:
+        raise ValueError("B must be 2-D or 3-D")
+    if kb != k:
+        raise ValueError(f"inner dimensions differ: {k} vs {kb}")
+    if out is None:
+        out = torch.empty(oshape, dtype=dt, device=A.device)
+    check(
+        lib.qs_matmul(
+            dtype_code(dt), A.data_ptr(), B.data_ptr(), out.data_ptr(),
+            m, n, k, k, n, n, batch, 0, k * n, m * n, _stream(),
+        ),
+        "qs_matmul",
+    )
+    return out
+
+
+def transform_two_body(u, C, C_tilde=None, out=None):
+    """out[pqrs] = Ct[pa] Ct[qb] u[abcd] C[cr] C[ds]  (basis_set.py:336-350)."""
+    lib = _lib.load()
+    if C_tilde is None:
+        C_tilde = default_bra(C)
+    dt = result_dtype(u, C, C_tilde)
+    u = _dev(u, dt)
+    C = _dev(C, dt)
+    Ct = _dev(C_tilde, dt)
+    L, M = C.shape
+    if tuple(u.shape) != (L, L, L, L):
+        raise ValueError(f"u has shape {tuple(u.shape)}, C is {tuple(C.shape)}")
+    if tuple(Ct.shape) != (M, L):
+        raise ValueError(f"C_tilde has shape {tuple(Ct.shape)}, expected {(M, L)}")
+    code = dtype_code(dt)
+    nbytes = check(lib.qs_transform_two_body_workspace(code, L, M), "workspace query")
+    if out is None:
+        out = torch.empty((M, M, M, M), dtype=dt, device=u.device)
+    work = workspace.get(nbytes, u.device)
+    check(
+        lib.qs_transform_two_body(
+            code, u.data_ptr(), C.data_ptr(), Ct.data_ptr(), out.data_ptr(),
+            work.data_ptr(), work.numel(), L, M, _stream(),
+        ),
+        "qs_transform_two_body",
+    )
+    return out
+
+
+def transform_two_body_partial(u_slab, C, C_tilde=None, out=None):
+    """Contractions over d, c, b of a leading-index slab:
+    v[a,q,r,s] = Ct[qb] u[a,b,c,d] C[cr] C[ds] for the rows of the slab."""
+    lib = _lib.load()
+    if C_tilde is None:
+        C_tilde = default_bra(C)
+    dt = result_dtype(u_slab, C, C_tilde)
+    u_slab = _dev(u_slab, dt)
+    C = _dev(C, dt)
+    Ct = _dev(C_tilde, dt)
+    L, M = C.shape
+    rows = u_slab.shape[0]
+    if tuple(u_slab.shape[1:]) != (L, L, L):
+        raise ValueError("slab shape does not match C")
+    code = dtype_code(dt)
+    nbytes = check(
+        lib.qs_transform_two_body_partial_workspace(code, L, M, rows), "workspace query"
+    )
+    if out is None:
+        out = torch.empty((rows, M, M, M), dtype=dt, device=u_slab.device)
+    work = workspace.get(nbytes, u_slab.device)
+    check(
+        lib.qs_transform_two_body_partial(
+            code, u_slab.data_ptr(), C.data_ptr(), Ct.data_ptr(), out.data_ptr(),
+            work.data_ptr(), work.numel(), L, M, rows, _stream(),
+        ),
+        "qs_transform_two_body_partial",
+    )
+    return out
+
+
+def transform_one_body(h, C, C_tilde=None):
+    """``Ct @ (h @ C)`` for one (L,L) matrix or a stack (n,L,L)
+    (basis_set.py:329-334)."""
+    lib = _lib.load()
+    if C_tilde is None:
+        C_tilde = default_bra(C)
+    dt = result_dtype(h, C, C_tilde)
+    h = _dev(h, dt)
+    C = _dev(C, dt)
+    Ct = _dev(C_tilde, dt)
+    L, M = C.shape
+    single = h.dim() == 2
+    hs = h.reshape(-1, L, L) if not single else h.reshape(1, L, L)
+    if tuple(hs.shape[1:]) != (L, L) or tuple(Ct.shape) != (M, L):
+        raise ValueError("operand shapes do not match C")
+    nmat = hs.shape[0]
+    out = torch.empty((nmat, M, M), dtype=dt, device=h.device)
+    es = 16 if dt == _C128 else 8
+    work = workspace.get(nmat * L * M * es, h.device)
+    check(
+        lib.qs_transform_one_body(
+            dtype_code(dt), hs.data_ptr(), C.data_ptr(), Ct.data_ptr(), out.data_ptr(),
+            work.data_ptr(), work.numel(), nmat, L, M, _stream(),
+        ),
+        "qs_transform_one_body",
+    )
+    return out[0] if single else out.reshape(*h.shape[:-2], M, M)
+
+
+def antisymmetrize(u, out=None):
+    """``u - u.transpose(0,1,3,2)`` (basis_set.py:776-778); pass ``out=u`` for
+    the in-place form."""
+    lib = _lib.load()
+    dt = result_dtype(u)
+    src = _dev(u, dt)
+    l = src.shape[-1]
+    if src.dim() < 2 or src.shape[-2] != l:
+        raise ValueError("last two axes must be square")
+    npq = src.numel() // (l * l)
+    if out is None:
+        out = torch.empty_like(src)
+    elif out is u:
+        out = src
+    check(
+        lib.qs_antisymmetrize(dtype_code(dt), src.data_ptr(), out.data_ptr(), npq, l, _stream()),
+        "qs_antisymmetrize",
+    )
+    return out
+
+
+def spin_expand_two_body(u, antisymmetrize=False, out_dtype=None, p_lo=0, p_hi=None, out=None):
+    """Spin doubling of (l,l,l,l) -> rows [2 p_lo, 2 p_hi) of (2l,2l,2l,2l)
+    (basis_set.py:772-774), optionally fused with the anti-symmetrisation
+    (:776-778) and the complex cast (:634)."""
+    lib = _lib.load()
+    dt = result_dtype(u)
+    u = _dev(u, dt)
+    l = u.shape[0]
+    if tuple(u.shape) != (l, l, l, l):
+        raise ValueError("u must be (l,l,l,l)")
+    p_hi = l if p_hi is None else p_hi
+    odt = dt if out_dtype is None else out_dtype
+    shape = (2 * (p_hi - p_lo), 2 * l, 2 * l, 2 * l)
+    if out is None:
+        out = torch.empty(shape, dtype=odt, device=u.device)
+    elif tuple(out.shape) != shape or out.dtype != odt or not out.is_contiguous():
+        raise ValueError("bad output buffer")
+    check(
+        lib.qs_spin_expand_two_body(
+            dtype_code(dt), dtype_code(odt), u.data_ptr(), out.data_ptr(), l, p_lo, p_hi,
+            1 if antisymmetrize else 0, _stream(),
+        ),
+        "qs_spin_expand_two_body",
+    )
+    return out
+
+
+def add_spin_one_body(h, out_dtype=None):
+    """``kron(h, I2)`` for (l,l) or a stack (n,l,l) (basis_set.py:768-770)."""
+    lib = _lib.load()
+    dt = result_dtype(h)
+    h = _dev(h, dt)
+    l = h.shape[-1]
+    if h.shape[-2] != l:
+        raise ValueError("last two axes must be square")
+    nmat = h.numel() // (l * l)
+    odt = dt if out_dtype is None else out_dtype
+    out = torch.empty(tuple(h.shape[:-2]) + (2 * l, 2 * l), dtype=odt, device=h.device)
+    check(
+        lib.qs_add_spin_one_body(
+            dtype_code(dt), dtype_code(odt), h.data_ptr(), out.data_ptr(), nmat, l, _stream()
+        ),
+        "qs_add_spin_one_body",
+    )
+    return out
+
+
+def spin_squared_two_body(S, antisymmetrize=False, p_lo=0, p_hi=None):
+    """Two-body S^2 from the stacked (3,n,n) spin matrices
+    (basis_set.py:745-747)."""
+    lib = _lib.load()
+    S = _dev(S, _C128)
+    n = S.shape[-1]
+    if tuple(S.shape) != (3, n, n):
+        raise ValueError("S must be (3,n,n)")
+    p_hi = n if p_hi is None else p_hi
+    out = torch.empty((p_hi - p_lo, n, n, n), dtype=_C128, device=S.device)
+    check(
+        lib.qs_spin_squared_two_body(
+            S.data_ptr(), out.data_ptr(), n, p_lo, p_hi, 1 if antisymmetrize else 0, _stream()
+        ),
+        "qs_spin_squared_two_body",
+    )
+    return out
+
+
+def tuning_set(key, value):
+    check(_lib.load().qs_tuning_set(key.encode(), int(value)), "qs_tuning_set")
