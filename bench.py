@@ -1,0 +1,292 @@
+"""Headline benchmark: four-index transform of the two-body integrals.
+
+    python bench.py [--gpus N --steps K --warmup W] [--l 256] [--dtype f64|c128]
+                    [--layout replicated|sharded] [--gather] [--no-cpu-baseline]
+
+Metric (BASELINE.json): "4-index u transform TFLOP/s (fp64) at L orbitals".
+A step is ONE full transform out = Ct Ct u C C of a synthetic RandomBasisSet-
+shaped tensor resident in HBM (BASELINE.json configs[2]: real fp64, l=256,
+u = 34.4 GB, C = real orthogonal).  The work figure is the algorithmic
+8 l^5 flops (32 l^5 for complex128), whatever the kernels actually do.
+
+N > 1 (launched by torch.distributed.run, one rank per GPU, RCCL): the SAME
+l=256 problem, output sharded over its leading index p ("strong" scaling).
+Default layout: u replicated on every GPU, no collective on the data path
+(SURVEY 8e); --layout sharded keeps u sharded over its second index and does
+one all-to-all; --gather adds the all-gather that replicates the result.
+
+Prints ONE JSON line on rank 0.
+"""
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+MFMA_F64_PEAK_TFLOPS = 78.6   # 256 CU x 4 SIMD x 2048 flop / 64 clk x 2.4 GHz (MI355X_MICROARCH.md clocks)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--l", type=int, default=256)
+    ap.add_argument("--dtype", choices=["f64", "c128"], default="f64")
+    ap.add_argument("--layout", choices=["replicated", "sharded"], default="replicated")
+    ap.add_argument("--gather", action="store_true", help="include the all-gather of the result")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-l", type=int, default=96, help="size of the CPU-baseline sample")
+    ap.add_argument("--no-probes", action="store_true")
+    return ap.parse_args()
+
+
+def make_inputs(torch, l, dtype, device, seed=1234):
+    """RandomBasisSet-shaped synthetic u (uniform [0,1), symmetrised
+    u_pqrs = u_qpsr like random_basis.py:46-50) generated on the device slab
+    by slab, and a unitary C from a seeded QR."""
+    g = torch.Generator(device=device).manual_seed(seed)
+    u = torch.empty((l, l, l, l), dtype=dtype, device=device)
+    rdt = torch.float64
+    step = max(1, min(l, (1 << 28) // (l * l * l)))
+    for lo in range(0, l, step):
+        hi = min(l, lo + step)
+        blk = torch.rand((hi - lo, l, l, l), dtype=rdt, device=device, generator=g)
+        if dtype.is_complex:
+            blk = torch.complex(blk, torch.rand((hi - lo, l, l, l), dtype=rdt, device=device, generator=g))
+        u[lo:hi] = blk
+    # symmetrise in place pair by pair: u[p,q] <- (u[p,q] + u[q,p]^T)/2 over (r,s)
+    for p in range(l):
+        a = u[p, p:]                                  # (l-p, l, l)
+        b = u[p:, p].transpose(1, 2)                  # u[q,p,s,r] as [q][r][s]
+        sym = 0.5 * (a + b)
+        u[p, p:] = sym
+        u[p:, p] = sym.transpose(1, 2)
+    a = torch.randn((l, l), dtype=rdt, device=device, generator=g)
+    if dtype.is_complex:
+        a = torch.complex(a, torch.randn((l, l), dtype=rdt, device=device, generator=g))
+    C, _ = torch.linalg.qr(a)
+    C = C.contiguous()
+    Ct = C.conj().transpose(0, 1).resolve_conj().contiguous()
+    return u, C, Ct
+
+
+def identity_check(torch, u, out_rows, C, Ct, p_lo, seed=7):
+    """Size-independent parity property: contract both sides with
+    random vectors; O(l^4) each.  Returns the relative difference."""
+    l, dt = C.shape[0], u.dtype
+    g = torch.Generator(device=u.device).manual_seed(seed)
+    vs = [torch.randn(l, dtype=torch.float64, device=u.device, generator=g).to(dt) for _ in range(4)]
+    x, y, z, w = vs
+    pc = out_rows.shape[0]
+    lhs = torch.einsum("pqrs,p,q,r,s->", out_rows, x[p_lo:p_lo + pc], y, z, w)
+    # restrict the x-contraction to this rank's rows of Ct
+    xa = Ct[p_lo:p_lo + pc].transpose(0, 1) @ x[p_lo:p_lo + pc]
+    rhs = torch.einsum("abcd,a,b,c,d->", u, xa, Ct.transpose(0, 1) @ y, C @ z, C @ w)
+    return lhs, rhs
+
+
+def cpu_baseline(l):
+    """The oracle (NumPy restatement of basis_set.py:341-348) timed on the
+    host cores of this box on a bounded sample of the same workload."""
+    import numpy as np
+
+    from oracle import qs_oracle as orc
+
+    try:
+        from threadpoolctl import threadpool_info
+
+        infos = [i for i in threadpool_info() if i.get("user_api") == "blas"]
+        threads = max([i.get("num_threads", 1) for i in infos] or [1])
+        blas = ",".join(sorted({str(i.get("internal_api")) for i in infos})) or "unknown"
+    except Exception:
+        threads, blas = os.cpu_count() or 1, "unknown"
+    rng = np.random.default_rng(0)
+    u = rng.random((l, l, l, l))
+    u = 0.5 * (u + u.transpose(1, 0, 3, 2))
+    C, _ = np.linalg.qr(rng.standard_normal((l, l)))
+    t0 = time.perf_counter()
+    out = orc.transform_two_body(u, C)
+    dt = time.perf_counter() - t0
+    assert out.shape == (l, l, l, l)
+    flops = orc.transform_flops(l, l)
+    return {
+        "value": flops / dt / 1e12, "unit": "TFLOP/s", "cores": int(threads), "kind": "port",
+        "sample": f"one fp64 transform at l={l} ({flops/1e9:.1f} GFLOP, {dt:.1f} s), numpy "
+                  f"{np.__version__} tensordot x4 on {blas} with {threads} threads "
+                  f"(os.cpu_count={os.cpu_count()})",
+    }
+
+
+def main():
+    args = parse()
+    import torch
+    import torch.distributed as dist
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus != world:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch N>1 with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N")
+        args.gpus = world
+    assert torch.cuda.is_available(), "bench.py needs a GPU (no CPU path)"
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", device_id=device)
+
+    from quantum_systems_amd import _lib, kernels, sharded
+
+    lib = _lib.load()
+    l = args.l
+    dtype = torch.float64 if args.dtype == "f64" else torch.complex128
+    kf = 1 if args.dtype == "f64" else 4
+    flops = kf * 8 * l**5
+
+    u, C, Ct = make_inputs(torch, l, dtype, device)
+    part = sharded.SlabPartition(l, world)
+    p_lo, p_hi = part.bounds(rank)
+
+    if world == 1:
+        out = torch.empty_like(u)
+
+        def step():
+            return kernels.transform_two_body(u, C, Ct, out=out)
+        launches_per_step = 4
+        layout = "single"
+    elif args.layout == "replicated":
+        def step():
+            o = sharded.transform_two_body_replicated(u, C, Ct, rank, world)
+            if args.gather:
+                o = sharded.all_gather_slabs(o, l, rank, world)
+            return o
+        launches_per_step = 4
+        layout = "u replicated, out p-sharded" + (", +all-gather" if args.gather else ", no collective")
+    else:
+        b_lo, b_hi = part.bounds(rank)
+        ub = u[:, b_lo:b_hi].contiguous()
+        del u
+        torch.cuda.empty_cache()
+        u = None
+
+        def step():
+            o = sharded.transform_two_body_sharded(ub, C, Ct, rank, world)
+            if args.gather:
+                o = sharded.all_gather_slabs(o, l, rank, world)
+            return o
+        launches_per_step = 3 + world
+        layout = "u b-sharded, one all-to-all, out p-sharded" + (", +all-gather" if args.gather else "")
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    res = None
+    for _ in range(args.warmup):
+        res = step()
+    barrier()
+    ev0 = torch.cuda.Event(enable_timing=True)
+    ev1 = torch.cuda.Event(enable_timing=True)
+    t0 = time.perf_counter()
+    ev0.record()
+    for _ in range(args.steps):
+        res = step()
+    ev1.record()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    dev_elapsed = ev0.elapsed_time(ev1) * 1e-3       # same stream as the kernels
+    if world > 1:
+        t = torch.tensor([elapsed, dev_elapsed], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed, dev_elapsed = t[0].item(), t[1].item()
+
+    # parity property at full size on this rank's rows
+    if u is not None:
+        rows = res[p_lo:p_hi] if (world == 1 or args.gather) else res
+        lhs, rhs = identity_check(torch, u, rows, C, Ct, p_lo)
+        pair = torch.stack([lhs, rhs]).to(torch.complex128)
+        if world > 1:
+            pr = torch.view_as_real(pair).contiguous()
+            dist.all_reduce(pr)
+            pair = torch.view_as_complex(pr)
+        rel = (abs(pair[0] - pair[1]) / abs(pair[1])).item()
+    else:
+        rel = None
+
+    if rank != 0:
+        if world > 1:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
+
+    ms_per_step = elapsed / args.steps * 1e3
+    value = flops * args.steps / elapsed / 1e12
+    # dominant kernel = the MFMA GEMM: `launches_per_step` launches carry all the
+    # flops of a step; everything else on the stream is microseconds.
+    per_launch_s = dev_elapsed / (args.steps * launches_per_step)
+    achieved = (flops / world / launches_per_step) / per_launch_s / 1e12
+    roofline = {
+        "bound": "mfma", "achieved": achieved, "peak": MFMA_F64_PEAK_TFLOPS, "unit": "TFLOP/s",
+        "frac": achieved / MFMA_F64_PEAK_TFLOPS, "traffic": None,
+        "kernel": "qs::gemm_kernel (v_mfma_f64_16x16x4_f64)",
+        "flops_per_launch": flops / world / launches_per_step,
+        "avg_launch_ms": per_launch_s * 1e3,
+    }
+    prof = os.path.join(ROOT, "profiles", "traffic_latest.json")
+    if world == 1 and os.path.exists(prof):
+        try:
+            with open(prof) as f:
+                tr = json.load(f)
+            if tr.get("l") == l and tr.get("dtype") == args.dtype:
+                roofline["traffic"] = tr["hbm_bytes_per_launch"]
+                roofline["traffic_source"] = tr.get("source")
+        except Exception:
+            pass
+
+    probes = {}
+    if not args.no_probes:
+        st = torch.cuda.current_stream().cuda_stream
+        sink = torch.zeros(8, dtype=torch.float64, device=device)
+        blocks, iters = 256 * 8, 4000
+        lib.qs_probe_mfma_f64(sink.data_ptr(), blocks, iters, st)
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        lib.qs_probe_mfma_f64(sink.data_ptr(), blocks, iters, st)
+        e1.record()
+        torch.cuda.synchronize()
+        probes["mfma_f64_register_loop_tflops"] = blocks * 4 * iters * 8 * 2048 / (e0.elapsed_time(e1) * 1e-3) / 1e12
+
+    line = {
+        "metric": f"4-index u transform TFLOP/s ({'fp64' if kf == 1 else 'complex128'}) at L={l} orbitals",
+        "value": value, "unit": "TFLOP/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "strong",
+        "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+        "config": {
+            "workload": f"RandomBasisSet-shaped l={l} {args.dtype} four-index transform "
+                        f"(BASELINE.json configs[2]), u resident in HBM, C unitary",
+            "l": l, "flops_per_step": flops, "layout": layout,
+            "frac_of_mfma_peak": value / (MFMA_F64_PEAK_TFLOPS * world),
+        },
+        "roofline": roofline,
+        "parity": {"randomised_identity_rel_diff": rel, "bound": 1e-10},
+        "probes": probes,
+    }
+    if not args.no_cpu_baseline:
+        del res
+        line["cpu_baseline"] = cpu_baseline(args.cpu_l)
+    print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -60,6 +60,8 @@ const char* qs_last_hip_error(void);
  *   B[b] : (k, n), leading dimension ldb, batch stride stride_b (0 = shared)
  *   out[b]: (m, n), leading dimension ldc, batch stride stride_c
  * Strides and leading dimensions are in ELEMENTS of the dtype.
+ * accumulate != 0 computes out[b] += A[b] . B[b] (used to close a contraction
+ * whose summed index arrives in several slabs, see qs_transform_two_body_partial).
  * Replaces np.dot / np.tensordot over one index:
  *   transform_spf / transform_bra_spf   basis_set.py:321-327
  *   transform_one_body_elements         basis_set.py:329-334
@@ -69,7 +71,7 @@ int qs_matmul(int dtype, const void* A, const void* B, void* out,
               int64_t m, int64_t n, int64_t k,
               int64_t lda, int64_t ldb, int64_t ldc,
               int64_t batch, int64_t stride_a, int64_t stride_b,
-              int64_t stride_c, void* stream);
+              int64_t stride_c, int accumulate, void* stream);
 
 /*
  * Bytes of workspace qs_transform_two_body needs for u:(L,L,L,L) -> (M,M,M,M).

@@ -52,12 +52,21 @@ def transform_two_body(u, C, C_tilde=None):
     (0,3,1,2)), then the leading axis.
     """
     Ct = _bra(C, C_tilde)
+    t = transform_two_body_dcb(u, C, Ct)
+    return np.tensordot(Ct, t, axes=(1, 0))  # pa,aqrs->pqrs    :348
+
+
+def transform_two_body_dcb(u, C, C_tilde=None):
+    """The first three contractions (d, c, b) of basis_set.py:342-346 on any
+    block of leading-index rows: v[a,q,r,s] = Ct[q,b] u[a,b,c,d] C[c,r] C[d,s].
+    Rows of the leading index are independent here, which is what the sharded
+    layouts of the build rely on."""
+    Ct = _bra(C, C_tilde)
     t = np.tensordot(u, C, axes=(3, 0))  # abcd,ds->abcs        :342
     t = np.tensordot(t, C, axes=(2, 0))  # abcs,cr->absr        :344
     t = t.transpose(0, 1, 3, 2)  # ->abrs
     t = np.tensordot(t, Ct, axes=(1, 1))  # abrs,qb->arsq        :346
-    t = t.transpose(0, 3, 1, 2)  # ->aqrs
-    return np.tensordot(Ct, t, axes=(1, 0))  # pa,aqrs->pqrs    :348
+    return t.transpose(0, 3, 1, 2)  # ->aqrs
 
 
 def transform_two_body_einsum(u, C, C_tilde=None):

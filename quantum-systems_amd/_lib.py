@@ -24,7 +24,7 @@ SIGNATURES = {
     "qs_abi_version": (c_int, []),
     "qs_error_string": (ctypes.c_char_p, [c_int]),
     "qs_last_hip_error": (ctypes.c_char_p, []),
-    "qs_matmul": (c_int, [c_int, c_ptr, c_ptr, c_ptr] + [c_i64] * 10 + [c_ptr]),
+    "qs_matmul": (c_int, [c_int, c_ptr, c_ptr, c_ptr] + [c_i64] * 10 + [c_int, c_ptr]),
     "qs_transform_two_body_workspace": (c_i64, [c_int, c_i64, c_i64]),
     "qs_transform_two_body": (
         c_int, [c_int, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_i64, c_i64, c_i64, c_ptr]),

@@ -24,12 +24,12 @@ void note_hip_error(hipError_t e, const char* what) {
 
 static int gemm(int dtype, const void* A, const void* B, void* C, int64_t m, int64_t n, int64_t k,
                 int64_t lda, int64_t ldb, int64_t ldc, int64_t batch, int64_t sa, int64_t sb,
-                int64_t sc, hipStream_t s) {
+                int64_t sc, hipStream_t s, int accumulate = 0) {
     if (dtype == QS_F64)
         return gemm_f64((const double*)A, (const double*)B, (double*)C, m, n, k, lda, ldb, ldc, batch,
-                        sa, sb, sc, s);
+                        sa, sb, sc, accumulate, s);
     return gemm_c128((const double*)A, (const double*)B, (double*)C, m, n, k, lda, ldb, ldc, batch,
-                     sa, sb, sc, s);
+                     sa, sb, sc, accumulate, s);
 }
 
 static inline int64_t even_up(int64_t x) { return (x + 1) & ~int64_t(1); }
@@ -87,14 +87,14 @@ int qs_tuning_set(const char* key, int64_t value) {
 
 int qs_matmul(int dtype, const void* A, const void* B, void* out, int64_t m, int64_t n, int64_t k,
               int64_t lda, int64_t ldb, int64_t ldc, int64_t batch, int64_t stride_a,
-              int64_t stride_b, int64_t stride_c, void* stream) {
+              int64_t stride_b, int64_t stride_c, int accumulate, void* stream) {
     if (!dtype_ok(dtype)) return QS_ERR_BAD_DTYPE;
     if (!A || !B || !out) return QS_ERR_NULL_POINTER;
     const size_t es = elem_size(dtype);
     if (!aligned(A, es) || !aligned(B, es) || !aligned(out, es)) return QS_ERR_MISALIGNED;
     if (stride_a < 0 || stride_b < 0 || stride_c < 0) return QS_ERR_BAD_EXTENT;
     return gemm(dtype, A, B, out, m, n, k, lda, ldb, ldc, batch, stride_a, stride_b, stride_c,
-                (hipStream_t)stream);
+                (hipStream_t)stream, accumulate);
 }
 
 int64_t qs_transform_two_body_workspace(int dtype, int64_t L, int64_t M) {

@@ -37,10 +37,10 @@ inline int64_t cdiv(int64_t a, int64_t b) { return (a + b - 1) / b; }
 // Internal launchers (defined in qs_gemm_f64.hip / qs_gemm_c128.hip).
 int gemm_f64(const double* A, const double* B, double* C, int64_t m, int64_t n,
              int64_t k, int64_t lda, int64_t ldb, int64_t ldc, int64_t batch,
-             int64_t sa, int64_t sb, int64_t sc, hipStream_t stream);
+             int64_t sa, int64_t sb, int64_t sc, int accumulate, hipStream_t stream);
 int gemm_c128(const double* A, const double* B, double* C, int64_t m, int64_t n,
               int64_t k, int64_t lda, int64_t ldb, int64_t ldc, int64_t batch,
-              int64_t sa, int64_t sb, int64_t sc, hipStream_t stream);
+              int64_t sa, int64_t sb, int64_t sc, int accumulate, hipStream_t stream);
 
 // out (cols, rows) = in (rows, cols)^T, element = 8 or 16 bytes (tiny helper
 // for the coefficient matrices).

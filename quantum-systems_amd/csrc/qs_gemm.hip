@@ -53,6 +53,7 @@ struct GemmArgs {
     int m, n, k;
     int tiles_m, tiles_n;
     int group_along_m;   // 1: tiles that share a B panel (same n-tile) are adjacent
+    int accumulate;      // 1: C += A.B (C is read in the epilogue), 0: C = A.B
 };
 
 // Work index of a workgroup: XCD x gets the x-th contiguous chunk of the work
@@ -230,11 +231,16 @@ void gemm_kernel(const GemmArgs g) {
                 for (int j = 0; j < TN; ++j) {
                     const int col = ccol + j * 16;
                     if (col < N) {
-                        if constexpr (CX)
-                            *reinterpret_cast<f64x2*>(crow_ptr + 2 * (int64_t)col) =
-                                f64x2{acc[0][i][j][r], acc[1][i][j][r]};
-                        else
-                            crow_ptr[col] = acc[0][i][j][r];
+                        if constexpr (CX) {
+                            f64x2* dst = reinterpret_cast<f64x2*>(crow_ptr + 2 * (int64_t)col);
+                            f64x2 v = f64x2{acc[0][i][j][r], acc[1][i][j][r]};
+                            if (g.accumulate) v += *dst;
+                            *dst = v;
+                        } else {
+                            double v = acc[0][i][j][r];
+                            if (g.accumulate) v += crow_ptr[col];
+                            crow_ptr[col] = v;
+                        }
                     }
                 }
             }
@@ -269,7 +275,7 @@ int g_gemm_c128_cfg = 0;
 
 static bool fill_args(GemmArgs& g, const double* A, const double* B, double* C, int64_t m,
                       int64_t n, int64_t k, int64_t lda, int64_t ldb, int64_t ldc, int64_t batch,
-                      int64_t sa, int64_t sb, int64_t sc) {
+                      int64_t sa, int64_t sb, int64_t sc, int accumulate) {
     if (m <= 0 || n <= 0 || k <= 0 || batch <= 0) return false;
     if (m > INT32_MAX || n > INT32_MAX || k > INT32_MAX) return false;
     if (lda < k || ldb < n || ldc < n) return false;
@@ -278,6 +284,7 @@ static bool fill_args(GemmArgs& g, const double* A, const double* B, double* C, 
     g.sa = sa; g.sb = sb; g.sc = sc;
     g.m = (int)m; g.n = (int)n; g.k = (int)k;
     g.tiles_m = g.tiles_n = 0;
+    g.accumulate = accumulate ? 1 : 0;
     // Which operand is the stream that neighbouring tiles should share in L2:
     // a shared (stride-0) A, or a short-and-wide product, streams B.
     g.group_along_m = ((sa == 0 && batch > 1) || m < n) ? 1 : 0;
@@ -290,7 +297,7 @@ static int dispatch_f64(int cfg, const GemmArgs& g, int64_t batch, hipStream_t s
         case 1: return launch_one<2, 2, 4, 4, 16, MODE>(g, batch, s);   // 128 x 128, 2 WG/CU
         case 2: return launch_one<4, 1, 4, 4, 16, MODE>(g, batch, s);   // 256 x  64
         case 3: return launch_one<1, 4, 4, 4, 16, MODE>(g, batch, s);   //  64 x 256
-        case 4: return launch_one<1, 1, 4, 4, 16, MODE>(g, batch, s);   //  64 x  64, 1 wave
+        case 4: return launch_one<1, 4, 2, 4, 16, MODE>(g, batch, s);   //  32 x 256 (short slabs)
         case 5: return launch_one<2, 2, 2, 2, 16, MODE>(g, batch, s);   //  64 x  64, 4 waves
         case 6: return launch_one<4, 2, 4, 4, 16, MODE>(g, batch, s);   // 256 x 128, 8 waves
         case 7: return launch_one<2, 4, 4, 4, 16, MODE>(g, batch, s);   // 128 x 256, 8 waves
@@ -300,15 +307,16 @@ static int dispatch_f64(int cfg, const GemmArgs& g, int64_t batch, hipStream_t s
 
 int gemm_f64(const double* A, const double* B, double* C, int64_t m, int64_t n, int64_t k,
              int64_t lda, int64_t ldb, int64_t ldc, int64_t batch, int64_t sa, int64_t sb,
-             int64_t sc, hipStream_t stream) {
+             int64_t sc, int accumulate, hipStream_t stream) {
     GemmArgs g;
-    if (!fill_args(g, A, B, C, m, n, k, lda, ldb, ldc, batch, sa, sb, sc)) return QS_ERR_BAD_EXTENT;
+    if (!fill_args(g, A, B, C, m, n, k, lda, ldb, ldc, batch, sa, sb, sc, accumulate))
+        return QS_ERR_BAD_EXTENT;
     // 16-byte loads need even extents/strides and 16-byte aligned bases.
     const bool vec = aligned(A, 16) && aligned(B, 16) && !(lda & 1) && !(ldb & 1) && !(k & 1) &&
                      !(n & 1) && !(sa & 1) && !(sb & 1);
     int cfg = g_gemm_f64_cfg;
     if (cfg == 0) {
-        if (m <= 64 && n <= 64) cfg = (batch >= 2048) ? 4 : 5;
+        if (m <= 64 && n <= 64) cfg = 5;
         else if (n <= 64) cfg = 2;
         else if (m <= 64) cfg = 3;
         else cfg = 1;
@@ -319,9 +327,10 @@ int gemm_f64(const double* A, const double* B, double* C, int64_t m, int64_t n, 
 
 int gemm_c128(const double* A, const double* B, double* C, int64_t m, int64_t n, int64_t k,
               int64_t lda, int64_t ldb, int64_t ldc, int64_t batch, int64_t sa, int64_t sb,
-              int64_t sc, hipStream_t stream) {
+              int64_t sc, int accumulate, hipStream_t stream) {
     GemmArgs g;
-    if (!fill_args(g, A, B, C, m, n, k, lda, ldb, ldc, batch, sa, sb, sc)) return QS_ERR_BAD_EXTENT;
+    if (!fill_args(g, A, B, C, m, n, k, lda, ldb, ldc, batch, sa, sb, sc, accumulate))
+        return QS_ERR_BAD_EXTENT;
     int cfg = g_gemm_c128_cfg;
     if (cfg == 0) {
         if (m <= 32 && n <= 32) cfg = 4;

@@ -45,6 +45,8 @@ def result_dtype(*tensors):
     """NumPy-style promotion restricted to {float64, complex128}."""
     out = _F64
     for t in tensors:
+        if not isinstance(t, torch.Tensor):
+            raise TypeError(f"expected a torch.Tensor, got {type(t).__name__}")
         if t.dtype in (torch.complex64, _C128):
             out = _C128
         elif t.dtype not in (_F64, torch.float32, torch.int64, torch.int32):
@@ -54,6 +56,8 @@ def result_dtype(*tensors):
 
 def default_bra(C):
     """``C.conj().T`` materialised (basis_set.py:331-332, 338-339)."""
+    if not isinstance(C, torch.Tensor):
+        raise TypeError(f"expected a torch.Tensor, got {type(C).__name__}")
     return C.conj().transpose(0, 1).resolve_conj().contiguous()
 
 
@@ -83,10 +87,26 @@ class Workspace:
 workspace = Workspace()
 
 
-def matmul(A, B, out=None):
-    """Row-major ``A @ B`` for 2-D operands (or a shared 2-D ``A`` against a
-    batch ``B`` of shape (batch, k, n))."""
+def gemm_raw(dt, A, B, out, m, n, k, lda, ldb, ldc, batch=1, sa=0, sb=0, sc=0,
+             accumulate=False, a_off=0, b_off=0, c_off=0):
+    """Thin call of ``qs_matmul`` on tensors already prepared by the caller
+    (contiguous storage, matching dtype); offsets and strides in elements."""
     lib = _lib.load()
+    es = 16 if dt == _C128 else 8
+    check(
+        lib.qs_matmul(
+            dtype_code(dt), A.data_ptr() + a_off * es, B.data_ptr() + b_off * es,
+            out.data_ptr() + c_off * es, m, n, k, lda, ldb, ldc, batch, sa, sb, sc,
+            1 if accumulate else 0, _stream(),
+        ),
+        "qs_matmul",
+    )
+    return out
+
+
+def matmul(A, B, out=None, accumulate=False):
+    """Row-major ``A @ B`` for 2-D operands (or a shared 2-D ``A`` against a
+    batch ``B`` of shape (batch, k, n)); ``accumulate`` adds into ``out``."""
     dt = result_dtype(A, B)
     A = _dev(A, dt)
     B = _dev(B, dt)
@@ -104,15 +124,12 @@ def matmul(A, B, out=None):
     if kb != k:
         raise ValueError(f"inner dimensions differ: {k} vs {kb}")
     if out is None:
+        if accumulate:
+            raise ValueError("accumulate needs an output buffer")
         out = torch.empty(oshape, dtype=dt, device=A.device)
-    check(
-        lib.qs_matmul(
-            dtype_code(dt), A.data_ptr(), B.data_ptr(), out.data_ptr(),
-            m, n, k, k, n, n, batch, 0, k * n, m * n, _stream(),
-        ),
-        "qs_matmul",
-    )
-    return out
+    elif out.dtype != dt or out.numel() != batch * m * n or not out.is_contiguous():
+        raise ValueError("bad output buffer")
+    return gemm_raw(dt, A, B, out, m, n, k, k, n, n, batch, 0, k * n, m * n, accumulate)
 
 
 def transform_two_body(u, C, C_tilde=None, out=None):

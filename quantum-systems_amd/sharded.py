@@ -1,0 +1,187 @@
+"""Sharding of the four-index transform over the GPUs of one node
+(one process per GPU, ``torch.distributed`` with the ``nccl`` backend = RCCL
+over xGMI; ``gloo`` in the CPU tests).
+
+The reference has no parallelism at all; this layer exists so the
+same ``transform_two_body_elements`` call scales past one device.  Two layouts,
+both producing the result sharded over its LEADING index ``p``
+(``out[p_lo:p_hi, :, :, :]`` on each rank, contiguous):
+
+``transform_two_body_replicated``
+    ``u`` is resident on every rank (l=256 fp64: 34 GB of 288 GB).  Rank g
+    contracts ``a`` first with its rows of ``Ct`` and then d, c, b on its own
+    slab.  No collective on the data path; 8 l^5 / G flops per rank.
+    ``all_gather_slabs`` replicates the p-sharded result when a caller wants
+    the whole tensor everywhere (the single all-gather of the north star).
+
+``transform_two_body_sharded``
+    ``u`` is sharded over its SECOND index (``u[:, b_lo:b_hi]``), so it never
+    has to fit on one device (l=512 complex128 = 1.1 TB).  d, c and a are
+    contracted locally -- ``a`` is fully local in this layout -- then ONE
+    all-to-all re-shards ``[p, b_loc] -> [p_loc, b]`` (per-rank traffic
+    (G-1)/G^2 * l^4 elements, G times less than an all-gather of the
+    intermediate) and the contraction over b closes on the received slabs.
+
+The contraction order differs from the reference's d, c, b, a only in where the
+``a`` sum sits; every element is still the same four sums, and parity is
+checked to the same 1e-10 bound.
+
+All arithmetic goes through an *engine* with two methods (``matmul`` and
+``partial``).  The only engine in the package is the HIP one below; the CPU
+tests inject their own (oracle-backed) engine to exercise partitioning and the
+exchange under ``gloo`` with world_size 2.
+"""
+
+import torch
+import torch.distributed as dist
+
+from . import kernels
+
+
+class SlabPartition:
+    """Contiguous, balanced split of ``n`` rows over ``world`` ranks."""
+
+    def __init__(self, n, world):
+        if world < 1 or n < 1:
+            raise ValueError("need n >= 1 and world >= 1")
+        self.n, self.world = int(n), int(world)
+        base, extra = divmod(self.n, self.world)
+        self.starts = [r * base + min(r, extra) for r in range(self.world + 1)]
+
+    def bounds(self, rank):
+        return self.starts[rank], self.starts[rank + 1]
+
+    def count(self, rank):
+        lo, hi = self.bounds(rank)
+        return hi - lo
+
+
+class HipEngine:
+    """The product engine: every call lands in libqs_amd.so."""
+
+    name = "hip"
+
+    @staticmethod
+    def matmul(A, B, out=None, accumulate=False):
+        return kernels.matmul(A, B, out=out, accumulate=accumulate)
+
+    @staticmethod
+    def partial(u_slab, C, C_tilde):
+        return kernels.transform_two_body_partial(u_slab, C, C_tilde)
+
+
+def _bra(C, C_tilde):
+    return kernels.default_bra(C) if C_tilde is None else C_tilde
+
+
+def transform_two_body_replicated(u, C, C_tilde=None, rank=0, world=1, engine=HipEngine):
+    """Rows ``p_lo:p_hi`` of the transformed tensor from a replicated ``u``.
+
+    out[p_loc, q, r, s] = sum_bcd Ct[q,b] (sum_a Ct[p_loc,a] u[a,b,c,d]) C[c,r] C[d,s]
+    """
+    Ct = _bra(C, C_tilde)
+    L, M = C.shape
+    lo, hi = SlabPartition(M, world).bounds(rank)
+    if hi == lo:
+        return u.new_empty((0, M, M, M))
+    rows = Ct[lo:hi].contiguous()
+    w = engine.matmul(rows, u.reshape(L, L * L * L))          # (p_loc, bcd)
+    return engine.partial(w.reshape(hi - lo, L, L, L), C, Ct)  # (p_loc, q, r, s)
+
+
+def _as_real_flat(t):
+    """1-D float64 view for the collectives (complex -> interleaved pairs)."""
+    t = t.contiguous()
+    if t.is_complex():
+        t = torch.view_as_real(t)
+    return t.reshape(-1)
+
+
+def all_gather_slabs(out_slab, M, rank, world, group=None):
+    """Replicate the p-sharded result: returns the full (M,M,M,M) tensor.
+    One all-gather over the node (uneven slabs are padded to the largest)."""
+    part = SlabPartition(M, world)
+    if world == 1:
+        return out_slab
+    per_row = M * M * M
+    width = 2 if out_slab.is_complex() else 1
+    biggest = max(part.count(r) for r in range(world)) * per_row * width
+    send = torch.zeros(biggest, dtype=torch.float64, device=out_slab.device)
+    flat = _as_real_flat(out_slab)
+    send[: flat.numel()] = flat
+    recv = torch.empty(world * biggest, dtype=torch.float64, device=out_slab.device)
+    dist.all_gather_into_tensor(recv, send, group=group)
+    full = torch.empty((M, M, M, M), dtype=out_slab.dtype, device=out_slab.device)
+    full_flat = _as_real_flat(full)  # view of `full`
+    for r in range(world):
+        lo, hi = part.bounds(r)
+        n = (hi - lo) * per_row * width
+        full_flat[lo * per_row * width: lo * per_row * width + n] = recv[r * biggest: r * biggest + n]
+    return full
+
+
+def transform_two_body_sharded(u_bslab, C, C_tilde=None, rank=0, world=1, group=None,
+                               engine=HipEngine):
+    """p-slab of the transform from a ``u`` sharded over its second index.
+
+    ``u_bslab = u[:, b_lo:b_hi, :, :]`` (contiguous) with the balanced split of
+    ``SlabPartition(L, world)``.  Returns ``out[p_lo:p_hi]`` with the split of
+    ``SlabPartition(M, world)``.  Exactly one collective (all-to-all).
+    """
+    Ct = _bra(C, C_tilde)
+    L, M = C.shape
+    bpart, ppart = SlabPartition(L, world), SlabPartition(M, world)
+    b_lo, b_hi = bpart.bounds(rank)
+    bl = b_hi - b_lo
+    if tuple(u_bslab.shape) != (L, bl, L, L):
+        raise ValueError(f"rank {rank}: slab shape {tuple(u_bslab.shape)}, expected {(L, bl, L, L)}")
+    dt = kernels.result_dtype(u_bslab, C, Ct)
+    u_bslab, C, Ct = u_bslab.to(dt), C.to(dt), Ct.to(dt)
+    width = 2 if dt.is_complex else 1
+    p_lo, p_hi = ppart.bounds(rank)
+    pc = p_hi - p_lo
+
+    if bl > 0:
+        # d:  T1[(a,b,c), s] = u[(a,b,c), d] C[d, s]
+        t1 = engine.matmul(u_bslab.reshape(L * bl * L, L), C)
+        # c:  T2[(a,b)][r, s] = CT[r, c] T1[(a,b)][c, s]
+        CT = C.transpose(0, 1).contiguous()
+        t2 = engine.matmul(CT, t1.reshape(L * bl, L, M))
+        del t1
+        # a:  X[p, (b,r,s)] = Ct[p, a] T2[a, (b,r,s)]      (a is local in this layout)
+        x = engine.matmul(Ct, t2.reshape(L, bl * M * M))
+        del t2
+    else:
+        x = u_bslab.new_empty((M, 0), dtype=dt)
+
+    if world == 1:
+        recv_blocks = [x.reshape(M, bl, M * M)]
+    else:
+        # one all-to-all: rows p of X go to the owner of p; we receive, from every
+        # source g, the block [p_loc, b in slab(g), (r,s)]
+        send = _as_real_flat(x)
+        in_splits = [ppart.count(g) * bl * M * M * width for g in range(world)]
+        out_splits = [pc * bpart.count(g) * M * M * width for g in range(world)]
+        recv = torch.empty(sum(out_splits), dtype=torch.float64, device=send.device)
+        dist.all_to_all_single(recv, send, out_splits, in_splits, group=group)
+        del x, send
+        recv_blocks, off = [], 0
+        for g in range(world):
+            blk = recv[off: off + out_splits[g]]
+            off += out_splits[g]
+            if width == 2:
+                blk = torch.view_as_complex(blk.reshape(-1, 2))
+            recv_blocks.append(blk.reshape(pc, bpart.count(g), M * M))
+
+    # b:  out[p][q, (r,s)] = sum_g Ct[q, b in slab(g)] R_g[p][b, (r,s)]
+    out = torch.empty((pc, M, M * M), dtype=dt, device=u_bslab.device)
+    if pc == 0:
+        return out.reshape(0, M, M, M)
+    first = True
+    for g in range(world):
+        g_lo, g_hi = bpart.bounds(g)
+        if g_hi == g_lo:
+            continue
+        engine.matmul(Ct[:, g_lo:g_hi].contiguous(), recv_blocks[g], out=out, accumulate=not first)
+        first = False
+    return out.reshape(pc, M, M, M)

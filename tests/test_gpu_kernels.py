@@ -1,0 +1,307 @@
+"""Parity of the HIP path (through the C ABI) against the CPU oracle and the
+committed golden vectors.  Needs a real MI355X: ``-m gpu``.
+
+Tolerances: floating-point transforms <= 1e-10 relative (BASELINE.json
+north_star; in practice ~1e-15), index/scatter work value-exact
+(``np.array_equal``: -0.0 == +0.0).
+"""
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import qs_oracle as orc
+
+pytestmark = pytest.mark.gpu
+
+RTOL = 1e-10
+
+
+@pytest.fixture(scope="module")
+def K():
+    assert torch.cuda.is_available(), "GPU tests need a GPU"
+    from quantum_systems_amd import kernels
+
+    return kernels
+
+
+def dev(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).to("cuda:0")
+
+
+def host(t):
+    return t.cpu().numpy()
+
+
+def relerr(got, ref):
+    return np.abs(got - ref).max() / max(np.abs(ref).max(), 1e-300)
+
+
+def crand(rng, *shape):
+    return rng.random(shape) + 1j * rng.random(shape)
+
+
+# ------------------------------------------------------------------ golden
+
+
+@pytest.mark.parametrize(
+    "name",
+    [
+        "transform_c128_square",
+        "transform_c128_rect_ctilde",
+        "transform_c128_shrink",
+        "transform_f64_orthogonal",
+        "transform_f64_rect",
+        "transform_mixed_real_u_complex_C",
+    ],
+)
+def test_transform_golden(K, golden, name):
+    g = golden(name)
+    Ct = dev(g["C_tilde"]) if "C_tilde" in g else None
+    u = host(K.transform_two_body(dev(g["u"]), dev(g["C"]), Ct))
+    h = host(K.transform_one_body(dev(g["h"]), dev(g["C"]), Ct))
+    assert u.dtype == g["u_out"].dtype and u.shape == g["u_out"].shape
+    assert h.dtype == g["h_out"].dtype
+    assert relerr(u, g["u_out"]) <= RTOL
+    assert relerr(h, g["h_out"]) <= RTOL
+
+
+def test_spf_golden(K, golden):
+    g = golden("transform_spf")
+    L = g["C"].shape[0]
+    spf = g["spf"].reshape(L, -1)
+    got = host(K.matmul(dev(g["C"].T.copy()), dev(spf))).reshape(g["spf_out"].shape)
+    assert relerr(got, g["spf_out"]) <= RTOL
+    bra = g["bra_spf"].reshape(L, -1)
+    got = host(K.matmul(dev(g["C_tilde"]), dev(bra))).reshape(g["bra_out"].shape)
+    assert relerr(got, g["bra_out"]) <= RTOL
+
+
+@pytest.mark.parametrize("name", ["spin_statics_f64", "spin_statics_c128"])
+def test_spin_statics_golden(K, golden, name):
+    g = golden(name)
+    u = dev(g["u"])
+    assert np.array_equal(host(K.spin_expand_two_body(u)), g["u_spin"])
+    assert np.array_equal(host(K.spin_expand_two_body(u, antisymmetrize=True)), g["u_spin_as"])
+    assert np.array_equal(host(K.antisymmetrize(u)), g["u_as"])
+    # unfused route: expand then anti-symmetrise in place
+    us = K.spin_expand_two_body(u)
+    K.antisymmetrize(us, out=us)
+    assert np.array_equal(host(us), g["u_spin_as"])
+    if "h" in g:
+        assert np.array_equal(host(K.add_spin_one_body(dev(g["h"]))), g["h_spin"])
+    # fused complex cast
+    got = host(K.spin_expand_two_body(u, antisymmetrize=True, out_dtype=torch.complex128))
+    assert got.dtype == np.complex128
+    assert np.array_equal(got, g["u_spin_as"].astype(np.complex128))
+
+
+def test_config1_u_golden(K, golden):
+    g = golden("config1_l20_change_basis")
+    np.random.seed(int(g["seed"]))
+    st = orc.random_basis(20, 2)
+    C = g["C"]
+    got = host(K.transform_two_body(dev(st["u"]), dev(C)))
+    assert relerr(got, g["u"]) <= RTOL
+    np.testing.assert_allclose(got, g["u"], rtol=1e-10, atol=1e-12)
+    for k in ("h", "s"):
+        assert relerr(host(K.transform_one_body(dev(st[k]), dev(C))), g[k]) <= RTOL
+    pos = host(K.transform_one_body(dev(st["position"]), dev(C)))
+    assert pos.shape == g["position"].shape and relerr(pos, g["position"]) <= RTOL
+
+
+def test_spin_squared_two_body_golden(K, golden):
+    g = golden("gos_l5_default_spinors")
+    S = np.stack([g["gos_spin_x"], g["gos_spin_y"], g["gos_spin_z"]])
+    got = host(K.spin_squared_two_body(dev(S), antisymmetrize=True))
+    np.testing.assert_allclose(got, g["gos_spin_2_tb"], rtol=1e-13, atol=1e-14)
+    g = golden("gos_l4_custom_spinors_no_as")
+    S = np.stack([g["gos_spin_x"], g["gos_spin_y"], g["gos_spin_z"]])
+    got = host(K.spin_squared_two_body(dev(S), antisymmetrize=False))
+    np.testing.assert_allclose(got, g["gos_spin_2_tb"], rtol=1e-13, atol=1e-14)
+    # slab form
+    part = host(K.spin_squared_two_body(dev(S), antisymmetrize=False, p_lo=2, p_hi=5))
+    np.testing.assert_allclose(part, g["gos_spin_2_tb"][2:5], rtol=1e-13, atol=1e-14)
+
+
+# ------------------------------------------------ oracle on seeded inputs
+
+
+@pytest.mark.parametrize("cplx", [False, True])
+@pytest.mark.parametrize(
+    "L,M",
+    [(1, 1), (2, 3), (5, 5), (16, 16), (17, 13), (20, 20), (10, 18), (33, 32), (55, 55), (64, 64), (70, 40)],
+)
+def test_transform_vs_oracle(K, L, M, cplx):
+    rng = np.random.default_rng(1000 * L + M + cplx)
+    if cplx:
+        u, C, Ct = crand(rng, L, L, L, L) - 0.5, crand(rng, L, M) - 0.5, crand(rng, M, L)
+    else:
+        u = rng.standard_normal((L, L, L, L))
+        C = rng.standard_normal((L, M))
+        Ct = rng.standard_normal((M, L))
+    # default bra = C^dagger
+    got = host(K.transform_two_body(dev(u), dev(C)))
+    assert relerr(got, orc.transform_two_body(u, C)) <= RTOL
+    # explicit, unrelated C_tilde (bi-orthogonal bases)
+    got = host(K.transform_two_body(dev(u), dev(C), dev(Ct)))
+    assert relerr(got, orc.transform_two_body(u, C, Ct)) <= RTOL
+    h = u[0, 0]
+    assert relerr(host(K.transform_one_body(dev(h), dev(C), dev(Ct))),
+                  orc.transform_one_body(h, C, Ct)) <= RTOL
+
+
+def test_transform_reference_test_case(K):
+    # the reference's own check (tests/test_helper.py:38-69): l=10 complex,
+    # non-unitary C, against the 5-operand einsum, atol 1e-10
+    rng = np.random.default_rng(5)
+    l = 10
+    u, C = crand(rng, l, l, l, l), crand(rng, l, l)
+    ref = np.einsum("ls,kr,jq,ip,ijkl->pqrs", C, C, C.conj(), C.conj(), u, optimize=True)
+    got = host(K.transform_two_body(dev(u), dev(C)))
+    np.testing.assert_allclose(got, ref, atol=1e-10)
+    got2 = host(K.transform_two_body(dev(u), dev(C), dev(C.conj().T.copy())))
+    np.testing.assert_allclose(got, got2)
+
+
+def test_transform_does_not_touch_input_and_handles_views(K):
+    rng = np.random.default_rng(6)
+    l = 12
+    u, C = crand(rng, l, l, l, l), crand(rng, l, l)
+    du = dev(u)
+    keep = du.clone()
+    # lazy-conjugated, transposed view as C_tilde (torch's .conj() is a view)
+    dC = dev(C)
+    got = host(K.transform_two_body(du, dC, dC.conj().T))
+    assert torch.equal(du, keep)
+    assert relerr(got, orc.transform_two_body(u, C)) <= RTOL
+    # non-contiguous u view
+    big = dev(crand(rng, l, l, l, 2 * l))
+    view = big[..., ::2]
+    got = host(K.transform_two_body(view, dC))
+    assert relerr(got, orc.transform_two_body(host(view), C)) <= RTOL
+
+
+def test_partial_transform_matches_slab_of_full(K):
+    rng = np.random.default_rng(7)
+    L, M = 12, 9
+    u, C, Ct = crand(rng, L, L, L, L), crand(rng, L, M), crand(rng, M, L)
+    # v[a,q,r,s] = Ct[q,b] u[a,b,c,d] C[c,r] C[d,s]
+    ref = np.einsum("qb,abcd,cr,ds->aqrs", Ct, u, C, C, optimize=True)
+    got = host(K.transform_two_body_partial(dev(u[3:8]), dev(C), dev(Ct)))
+    assert relerr(got, ref[3:8]) <= RTOL
+    # closing the contraction over a with a plain product gives the full result
+    v = K.transform_two_body_partial(dev(u), dev(C), dev(Ct))
+    full = host(K.matmul(dev(Ct), v.reshape(L, -1))).reshape(M, M, M, M)
+    assert relerr(full, orc.transform_two_body(u, C, Ct)) <= RTOL
+
+
+@pytest.mark.parametrize("cplx", [False, True])
+@pytest.mark.parametrize("l", [1, 2, 7, 31, 32, 33, 64, 70])
+def test_antisymmetrize_vs_oracle(K, l, cplx):
+    rng = np.random.default_rng(l)
+    n = 3 if l > 32 else l
+    u = rng.standard_normal((n, n, l, l))
+    if cplx:
+        u = u + 1j * rng.standard_normal((n, n, l, l))
+    ref = u - u.transpose(0, 1, 3, 2)
+    d = dev(u)
+    assert np.array_equal(host(K.antisymmetrize(d)), ref)
+    K.antisymmetrize(d, out=d)  # in place
+    assert np.array_equal(host(d), ref)
+
+
+@pytest.mark.parametrize("l", [1, 3, 8, 33])
+@pytest.mark.parametrize("mode", ["f64", "c128", "f64->c128"])
+def test_spin_expand_vs_oracle(K, l, mode):
+    rng = np.random.default_rng(l)
+    u = rng.standard_normal((l, l, l, l))
+    odt = None
+    if mode == "c128":
+        u = u + 1j * rng.standard_normal((l, l, l, l))
+    if mode == "f64->c128":
+        odt = torch.complex128
+    us = orc.add_spin_two_body(u)
+    for anti in (False, True):
+        ref = orc.anti_symmetrize_u(us) if anti else us
+        if odt is not None:
+            ref = ref.astype(np.complex128)
+        got = host(K.spin_expand_two_body(dev(u), antisymmetrize=anti, out_dtype=odt))
+        assert got.dtype == ref.dtype and np.array_equal(got, ref)
+    # p-slab form writes rows [2 p_lo, 2 p_hi)
+    if l >= 3:
+        ref = orc.anti_symmetrize_u(us)
+        got = host(K.spin_expand_two_body(dev(u), antisymmetrize=True, p_lo=1, p_hi=3))
+        assert np.array_equal(got, ref[2:6])
+
+
+def test_spin_index_law_like_reference(K):
+    # reference tests/test_helper.py:87-135 (explicit spin_delta loops)
+    rng = np.random.default_rng(8)
+    u = rng.random((4, 4, 4, 4))
+    u = u + u.transpose(1, 0, 3, 2)
+    ref = orc.spin_two_body_index_law(u)
+    got = host(K.spin_expand_two_body(dev(u), antisymmetrize=True))
+    np.testing.assert_allclose(got, ref, atol=1e-10)
+    assert np.array_equal(got, ref)
+    # antisymmetry properties (tests/test_helper.py:138-147)
+    np.testing.assert_allclose(got, -got.transpose(0, 1, 3, 2), atol=1e-10)
+    np.testing.assert_allclose(got, -got.transpose(1, 0, 2, 3), atol=1e-10)
+    np.testing.assert_allclose(got, got.transpose(1, 0, 3, 2), atol=1e-10)
+
+
+def test_add_spin_one_body_vs_oracle(K):
+    rng = np.random.default_rng(9)
+    for shape in [(1, 1), (5, 5), (3, 6, 6)]:
+        h = rng.standard_normal(shape)
+        ref = (
+            np.stack([orc.add_spin_one_body(m) for m in h]) if h.ndim == 3 else orc.add_spin_one_body(h)
+        )
+        assert np.array_equal(host(K.add_spin_one_body(dev(h))), ref)
+        got = host(K.add_spin_one_body(dev(h), out_dtype=torch.complex128))
+        assert np.array_equal(got, ref.astype(np.complex128))
+
+
+# ----------------------------------------- larger sizes: properties only
+
+
+@pytest.mark.parametrize("dt", [torch.float64, torch.complex128])
+def test_randomised_identity_l96(K, dt):
+    # sum out.x(x)y(x)z(x)w == sum u.(Ct^T x)(x)(Ct^T y)(x)(C z)(x)(C w)   
+    l = 96
+    g = torch.Generator(device="cuda:0").manual_seed(3)
+    u = torch.rand(l, l, l, l, dtype=torch.float64, device="cuda:0", generator=g).to(dt)
+    C = torch.randn(l, l, dtype=torch.float64, device="cuda:0", generator=g).to(dt)
+    if dt == torch.complex128:
+        C = C + 1j * torch.randn(l, l, dtype=torch.float64, device="cuda:0", generator=g)
+    C = C / l**0.5
+    Ct = C.conj().T.contiguous()
+    out = K.transform_two_body(u, C, Ct)
+    x, y, z, w = (torch.randn(l, dtype=torch.float64, device="cuda:0", generator=g).to(dt) for _ in range(4))
+    lhs = torch.einsum("pqrs,p,q,r,s->", out, x, y, z, w)
+    rhs = torch.einsum("abcd,a,b,c,d->", u, Ct.T @ x, Ct.T @ y, C @ z, C @ w)
+    assert abs(lhs - rhs).item() <= 1e-10 * abs(rhs).item()
+    # linearity in u
+    out2 = K.transform_two_body(2.5 * u, C, Ct)
+    assert (out2 - 2.5 * out).abs().max().item() <= 1e-10 * out.abs().max().item()
+
+
+def test_unitary_round_trip_l64(K):
+    # transform with a unitary C then with C^dagger returns u
+    l = 64
+    g = torch.Generator(device="cuda:0").manual_seed(4)
+    u = torch.rand(l, l, l, l, dtype=torch.float64, device="cuda:0", generator=g)
+    Q, _ = torch.linalg.qr(torch.randn(l, l, dtype=torch.float64, device="cuda:0", generator=g))
+    back = K.transform_two_body(K.transform_two_body(u, Q), Q.T.contiguous())
+    assert (back - u).abs().max().item() <= 1e-10
+
+
+def test_bad_arguments_raise(K):
+    u = torch.zeros(4, 4, 4, 4, dtype=torch.float64, device="cuda:0")
+    C = torch.zeros(5, 4, dtype=torch.float64, device="cuda:0")
+    with pytest.raises(ValueError):
+        K.transform_two_body(u, C)
+    with pytest.raises(RuntimeError):
+        K.transform_two_body(u.cpu(), torch.zeros(4, 4, dtype=torch.float64))
+    with pytest.raises(TypeError):
+        K.antisymmetrize(u.to(torch.float16))
