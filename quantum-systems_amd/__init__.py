@@ -1,8 +1,27 @@
 """MI355X-native integral basis transformation behind the quantum-systems API.
 
-The directory is named ``quantum-systems_amd`` (with the hyphen of the upstream
-project); import it as ``quantum_systems_amd`` -- the sibling shim package of
-that name aliases this one -- or via ``importlib.import_module``.
+Drop-in for the hot path of HyQD/quantum-systems: the same ``BasisSet`` /
+``QuantumSystem`` classes, with the four-index transform, one-body transforms,
+anti-symmetrisation and spin doubling executed by hand-written HIP kernels
+(``libqs_amd.so``, C ABI in ``include/qs_amd.h``).  Pass ``array_module.hip``
+(exported here as ``hip``) wherever the reference takes ``np=`` to keep the
+tensors resident in HBM.
+
+The directory is named ``quantum-systems_amd`` after the upstream project;
+import it as ``quantum_systems_amd`` (the sibling shim package aliases it).
 """
 
-from . import _lib, kernels  # noqa: F401
+from . import _lib, kernels, sharded  # noqa: F401
+from .array_module import DeviceArray, DeviceModule, hip
+from .basis_set import BasisSet
+from .custom_system import construct_custom_system, setup_basis_set
+from .general_orbital_system import GeneralOrbitalSystem
+from .random_basis import RandomBasisSet
+from .spatial_orbital_system import SpatialOrbitalSystem
+from .system import QuantumSystem
+
+__all__ = [
+    "BasisSet", "RandomBasisSet", "QuantumSystem", "SpatialOrbitalSystem",
+    "GeneralOrbitalSystem", "setup_basis_set", "construct_custom_system",
+    "hip", "DeviceModule", "DeviceArray", "kernels", "sharded",
+]

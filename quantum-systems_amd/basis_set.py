@@ -1,0 +1,482 @@
+"""``BasisSet``: container of second-quantised matrix elements whose basis
+changes, anti-symmetrisation and spin doubling run on the MI355X.
+
+API mirror of the reference class (quantum_systems/basis_set.py): same
+constructor, attribute names, static-method signatures, mutation semantics and
+assertions, so code written against the reference runs unchanged.  What is
+different is where the arithmetic happens: every method that touches the
+rank-4 tensor (and the one-body transforms) hands device pointers to
+``libqs_amd.so``.  There is no NumPy implementation in this file:
+
+* with the device array module (``array_module.hip``) the arrays stay resident
+  in HBM between calls;
+* with plain ``numpy`` as the module (the reference's default) inputs are
+  staged to the GPU, computed there and copied back -- the same kernels, plus
+  PCIe.  Without a GPU these methods raise.
+
+Reference line numbers in the docstrings are those of
+quantum_systems/basis_set.py unless another file is named.
+"""
+
+import copy
+import warnings
+
+import numpy
+import torch
+
+from . import kernels
+from .array_module import convert, is_device_module, to_host, wrap
+from .system_helper import compute_particle_density
+
+_ARRAY_FIELDS = (
+    "_h", "_s", "_u", "_spf", "_bra_spf", "_position", "_momentum",
+    "_spin_x", "_spin_y", "_spin_z", "_spin_2", "_spin_2_tb",
+)
+
+
+def _stage(arr):
+    """Device tensor for a NumPy array, torch tensor or nested list."""
+    if isinstance(arr, torch.Tensor):
+        if arr.is_cuda:
+            return arr
+        return arr.cuda()
+    if not torch.cuda.is_available():
+        raise RuntimeError(
+            "quantum_systems_amd computes on the GPU only and no GPU is visible "
+            "(there is no CPU fallback for the transform path)"
+        )
+    return torch.from_numpy(numpy.ascontiguousarray(numpy.asarray(arr))).cuda()
+
+
+def _deliver(t, np):
+    """Hand a device result back in the caller's array module."""
+    if is_device_module(np):
+        return wrap(t)
+    return np.asarray(to_host(t))
+
+
+def _module_of(np):
+    return numpy if np is None else np
+
+
+class _Checked:
+    """Attribute whose every axis must equal ``owner.l`` (:87-115, :780-782)."""
+
+    def __init__(self, needs_spin=False, stacked=False, check=True):
+        self.needs_spin, self.stacked, self.check = needs_spin, stacked, check
+
+    def __set_name__(self, owner, name):
+        self.slot = "_" + name
+
+    def __get__(self, obj, objtype=None):
+        return self if obj is None else getattr(obj, self.slot)
+
+    def __set__(self, obj, value):
+        if self.needs_spin:
+            assert obj.includes_spin
+        if self.check:
+            if self.stacked:
+                assert len(value) == obj.dim
+                for block in value:
+                    assert all(obj.check_axis_lengths(block, obj.l))
+            else:
+                assert all(obj.check_axis_lengths(value, obj.l))
+        setattr(obj, self.slot, value)
+
+
+class BasisSet:
+    """Matrix elements ``h``, ``s``, ``u``, ``position``... of ``l`` basis
+    functions in ``dim`` dimensions, held by the array module ``np``.
+
+    Parameters follow the reference constructor (:32-34): ``l``, ``dim``,
+    ``np=None`` (NumPy), ``includes_spin=False``, ``anti_symmetrized_u=False``.
+    """
+
+    h = _Checked()
+    u = _Checked()
+    s = _Checked()
+    position = _Checked(stacked=True)
+    momentum = _Checked(stacked=True)
+    spin_x = _Checked(needs_spin=True)
+    spin_y = _Checked(needs_spin=True)
+    spin_z = _Checked(needs_spin=True)
+    spin_2 = _Checked(needs_spin=True)
+    sigma_x = _Checked(needs_spin=True, check=False)
+    sigma_y = _Checked(needs_spin=True, check=False)
+    sigma_z = _Checked(needs_spin=True, check=False)
+
+    def __init__(self, l, dim, np=None, includes_spin=False, anti_symmetrized_u=False):
+        self.np = _module_of(np)
+        self.l = l
+        self.dim = dim
+        self._grid = None
+        for slot in _ARRAY_FIELDS + ("_sigma_x", "_sigma_y", "_sigma_z"):
+            setattr(self, slot, None)
+        self._spin_2_tb_recipe = None
+        self._nuclear_repulsion_energy = 0
+        self.particle_charge = -1  # electrons
+        self._includes_spin = includes_spin
+        self._anti_symmetrized_u = anti_symmetrized_u
+
+    # ------------------------------------------------------------ plain props
+    @property
+    def includes_spin(self):
+        return self._includes_spin
+
+    @property
+    def anti_symmetrized_u(self):
+        return self._anti_symmetrized_u
+
+    @property
+    def grid(self):
+        return self._grid
+
+    @grid.setter
+    def grid(self, grid):
+        self._grid = grid
+
+    @property
+    def dipole_moment(self):
+        return self.particle_charge * self.position
+
+    @property
+    def nuclear_repulsion_energy(self):
+        return self._nuclear_repulsion_energy
+
+    @nuclear_repulsion_energy.setter
+    def nuclear_repulsion_energy(self, value):
+        self._nuclear_repulsion_energy = value
+
+    @property
+    def spf(self):
+        return self._spf
+
+    @spf.setter
+    def spf(self, spf):
+        if spf is not None:
+            assert spf.shape[0] == self.l
+            assert len(tuple(spf.shape[1:])) == self.dim
+        self._spf = spf
+
+    @property
+    def bra_spf(self):
+        # Hermitian basis: the dual functions are the conjugates (:244-250)
+        if self._bra_spf is None and self._spf is not None:
+            self._bra_spf = self._spf.conj()
+        return self._bra_spf
+
+    @bra_spf.setter
+    def bra_spf(self, bra_spf):
+        if bra_spf is not None:
+            assert bra_spf.shape[0] == self.l
+            assert len(tuple(bra_spf.shape[1:])) == self.dim
+        self._bra_spf = bra_spf
+
+    @property
+    def spin_2_tb(self):
+        """Two-body S^2.  At (2l)^4 complex elements it is as large as ``u``;
+        the spin doubling records how to build it and the tensor is produced on
+        first access (SURVEY 7 "memory capacity")."""
+        if self._spin_2_tb is None and self._spin_2_tb_recipe is not None:
+            stack, anti = self._spin_2_tb_recipe
+            self._spin_2_tb_recipe = None
+            self._spin_2_tb = _deliver(
+                kernels.spin_squared_two_body(_stage(stack), antisymmetrize=anti), self.np
+            )
+        return self._spin_2_tb
+
+    @spin_2_tb.setter
+    def spin_2_tb(self, value):
+        assert self.includes_spin
+        assert all(self.check_axis_lengths(value, self.l))
+        self._spin_2_tb_recipe = None
+        self._spin_2_tb = value
+
+    # --------------------------------------------------------- module plumbing
+    @staticmethod
+    def change_arr_module(arr, np):
+        return convert(arr, np)
+
+    def change_module(self, np):
+        """Re-home every stored array in ``np`` (:272-296).  NumPy -> device
+        uploads, device -> NumPy downloads."""
+        self.np = np
+        self.bra_spf  # materialise the lazy dual before converting, as :287 does
+        for slot in _ARRAY_FIELDS:
+            setattr(self, slot, convert(getattr(self, slot), np))
+        if self._spin_2_tb_recipe is not None:
+            stack, anti = self._spin_2_tb_recipe
+            self._spin_2_tb_recipe = (convert(stack, np), anti)
+
+    def cast_to_complex(self):
+        """Every stored array -> complex128 (:298-319)."""
+        np = self.np
+        self.bra_spf
+        for slot in _ARRAY_FIELDS:
+            arr = getattr(self, slot)
+            if arr is not None:
+                setattr(self, slot, arr.astype(np.complex128))
+
+    def copy_basis(self):
+        """Deep copy (:784-805); device arrays are cloned on the device."""
+        np = self.np
+        self.np = None
+        try:
+            new = copy.deepcopy(self)
+        finally:
+            self.np = np
+        new.np = np
+        return new
+
+    # ------------------------------------------------------------- transforms
+    @staticmethod
+    def transform_spf(spf, C, np):
+        """spf'[p, g] = sum_a C[a, p] spf[a, g] (:321-323)."""
+        d_spf, d_C = _stage(spf), _stage(C)
+        L = d_C.shape[0]
+        out = kernels.matmul(d_C.transpose(0, 1), d_spf.reshape(L, -1))
+        return _deliver(out.reshape((d_C.shape[1],) + tuple(d_spf.shape[1:])), np)
+
+    @staticmethod
+    def transform_bra_spf(bra_spf, C_tilde, np):
+        """bra'[p, g] = sum_a Ct[p, a] bra[a, g] (:325-327)."""
+        d_bra, d_Ct = _stage(bra_spf), _stage(C_tilde)
+        L = d_Ct.shape[1]
+        out = kernels.matmul(d_Ct, d_bra.reshape(L, -1))
+        return _deliver(out.reshape((d_Ct.shape[0],) + tuple(d_bra.shape[1:])), np)
+
+    @staticmethod
+    def transform_one_body_elements(h, C, np, C_tilde=None):
+        """``Ct (h C)`` with ``Ct = C^dagger`` unless given (:329-334)."""
+        Ct = None if C_tilde is None else _stage(C_tilde)
+        return _deliver(kernels.transform_one_body(_stage(h), _stage(C), Ct), np)
+
+    @staticmethod
+    def transform_two_body_elements(u, C, np, C_tilde=None):
+        """out[pqrs] = Ct[pa] Ct[qb] u[abcd] C[cr] C[ds] (:336-350), four
+        single-index contractions in the reference's order d, c, b, a.  Returns
+        a new array; ``u`` is left untouched."""
+        Ct = None if C_tilde is None else _stage(C_tilde)
+        return _deliver(kernels.transform_two_body(_stage(u), _stage(C), Ct), np)
+
+    def get_transformed_h(self, C):
+        return self.transform_one_body_elements(self.h, C, np=self.np)
+
+    def get_transformed_u(self, C):
+        return self.transform_two_body_elements(self.u, C, np=self.np)
+
+    def change_basis(self, C, C_tilde=None):
+        """In-place change of basis with ket coefficients ``C`` (l_old, l_new)
+        and bra coefficients ``C_tilde`` (l_new, l_old), default ``C^dagger``
+        (:413-464).  Rectangular ``C`` changes ``l``."""
+        np = self.np
+        self.l = C.shape[1]                                     # :448
+        d_C = _stage(C)
+        d_Ct = kernels.default_bra(d_C) if C_tilde is None else _stage(C_tilde)
+
+        def one_body(arr):
+            return _deliver(kernels.transform_one_body(_stage(arr), d_C, d_Ct), np)
+
+        self.h = one_body(self.h)
+        if self.s is not None:
+            self.s = one_body(self.s)
+        # :368-372 transforms spin_x/y/z/spin_2 into a loop local and drops
+        # the result; they keep their old values (and shapes) here as well.
+
+        old_u = self._u
+        self._u = None  # let the old tensor go as soon as the new one exists
+        self.u = _deliver(kernels.transform_two_body(_stage(old_u), d_C, d_Ct), np)
+        del old_u
+        if self.spin_2_tb is not None:                          # :379-382
+            old = self._spin_2_tb
+            self._spin_2_tb = None
+            self.spin_2_tb = _deliver(kernels.transform_two_body(_stage(old), d_C, d_Ct), np)
+            del old
+
+        if self.position is not None:
+            self.position = one_body(self.position)             # stacked (dim, l, l)
+        if self.momentum is not None:
+            self.momentum = one_body(self.momentum)
+        if self.spf is not None:
+            bra = self.transform_bra_spf(self.bra_spf, d_Ct, np)
+            ket = self.transform_spf(self.spf, d_C, np)
+            self.bra_spf = bra
+            self.spf = ket
+
+    def compute_particle_density(self, rho_qp, C=None, C_tilde=None):
+        """rho(r) = bra_q(r) rho_qp ket_p(r), optionally in a rotated basis
+        (:466-509)."""
+        assert (
+            self._spf is not None
+        ), "Set up single-particle functions prior to calling this function"
+        ket, bra = self.spf, self.bra_spf
+        if C is not None:
+            ket = self.transform_spf(ket, C, self.np)
+            C_tilde = C_tilde if C_tilde is not None else C.conj().T
+            bra = self.transform_bra_spf(bra, C_tilde, self.np)
+        return compute_particle_density(rho_qp, ket, bra, self.np)
+
+    # ------------------------------------------- anti-symmetry and spin doubling
+    @staticmethod
+    def anti_symmetrize_u(_u):
+        """``u[pqrs] - u[pqsr]`` as a new array (:776-778)."""
+        out = kernels.antisymmetrize(_stage(_u))
+        if isinstance(_u, torch.Tensor):
+            return wrap(out)
+        return to_host(out)
+
+    def anti_symmetrize_two_body_elements(self):
+        """Anti-symmetrise ``u`` and ``spin_2_tb`` once (:511-528)."""
+        if self._anti_symmetrized_u:
+            return
+        d = _stage(self.u)
+        on_device = d is self.u or isinstance(self.u, torch.Tensor)
+        res = kernels.antisymmetrize(d, out=d if not on_device else None)
+        self.u = _deliver(res, self.np)
+        if self._spin_2_tb_recipe is not None:
+            stack, _ = self._spin_2_tb_recipe
+            self._spin_2_tb_recipe = (stack, True)
+        elif self._spin_2_tb is not None:
+            self.spin_2_tb = _deliver(kernels.antisymmetrize(_stage(self._spin_2_tb)), self.np)
+        self._anti_symmetrized_u = True
+
+    @staticmethod
+    def add_spin_one_body(h, np):
+        """``kron(h, I2)`` (:768-770)."""
+        return _deliver(kernels.add_spin_one_body(_stage(h)), np)
+
+    @staticmethod
+    def add_spin_two_body(_u, np):
+        """``kron(u, delta_pr delta_qs)`` (:772-774): 16x the elements, 4 of 16
+        spin blocks non-zero."""
+        return _deliver(kernels.spin_expand_two_body(_stage(_u)), np)
+
+    @staticmethod
+    def add_spin_spf(spf, np):
+        """Each spatial function appears once per spin direction: rows
+        interleaved (:751-759)."""
+        d = _stage(spf)
+        out = torch.repeat_interleave(d, 2, dim=0)
+        return _deliver(out, np)
+
+    @staticmethod
+    def add_spin_bra_spf(bra_spf, np):
+        if bra_spf is None:
+            return None
+        return BasisSet.add_spin_spf(bra_spf, np)
+
+    @staticmethod
+    def setup_pauli_matrices(a, b, np):
+        """Pauli matrices in the orthonormal spinor basis {a, b} (column
+        vectors): element [i, j] = <s_i| sigma |s_j> (:638-697).
+
+        >>> import numpy as np
+        >>> a = np.array([1, 0]).reshape(-1, 1)
+        >>> b = np.array([0, 1]).reshape(-1, 1)
+        >>> sx, sy, sz = BasisSet.setup_pauli_matrices(a, b, np)
+        >>> print(sz)
+        [[ 1.+0.j  0.+0.j]
+         [ 0.+0.j -1.+0.j]]
+        """
+        sv = numpy.concatenate(
+            [to_host(a).reshape(2, 1), to_host(b).reshape(2, 1)], axis=1
+        ).astype(numpy.complex128)                 # columns a, b
+        paulis = (
+            numpy.array([[0, 1], [1, 0]], dtype=numpy.complex128),
+            numpy.array([[0, -1j], [1j, 0]], dtype=numpy.complex128),
+            numpy.array([[1, 0], [0, -1]], dtype=numpy.complex128),
+        )
+        # 2x2 bookkeeping, done on the host
+        out = tuple(sv.conj().T @ (sig @ sv) for sig in paulis)
+        return tuple(convert(m, np) for m in out)
+
+    @staticmethod
+    def setup_spin_squared_operator(spin_x, spin_y, spin_z, overlap, np):
+        """One-body ``sum_i S_i s S_i`` and two-body
+        ``sum_i S_i[pr] S_i[qs]`` parts of S^2 (:699-749)."""
+        stack = torch.stack([_stage(spin_x), _stage(spin_y), _stage(spin_z)]).to(torch.complex128)
+        d_s = _stage(overlap).to(torch.complex128)
+        spin_2 = None
+        for k in range(3):  # same accumulation order as :745-746
+            term = kernels.matmul(stack[k], kernels.matmul(d_s, stack[k]))
+            spin_2 = term if spin_2 is None else spin_2 + term
+        tb = kernels.spin_squared_two_body(stack, antisymmetrize=False)
+        return _deliver(spin_2, np), _deliver(tb, np)
+
+    def change_to_general_orbital_basis(self, a=[1, 0], b=[0, 1], anti_symmetrize=True):
+        """Spin doubling in place (:530-636): every spatial orbital becomes an
+        alpha and a beta spin orbital (index P = 2p + sigma), ``u`` gets the
+        delta-Kronecker expansion (fused here with the anti-symmetrisation and
+        the complex cast: one read of ``u``, one write of the 16x tensor), spin
+        operators are set up in the spinor basis {a, b} and all arrays end up
+        complex128.  Returns ``self``; warns and returns ``None`` when the basis
+        already carries spin."""
+        if self._includes_spin:
+            warnings.warn(
+                "The basis has already been spin-doubled. Avoiding a second doubling."
+            )
+            return None
+        np = self.np
+        c128 = torch.complex128
+        self._includes_spin = True
+        self.l = 2 * self.l
+
+        d_overlap = _stage(self.s)
+        d_h = kernels.add_spin_one_body(_stage(self.h), out_dtype=c128)
+        d_s = kernels.add_spin_one_body(d_overlap, out_dtype=c128)
+
+        anti_now = bool(anti_symmetrize) and not self._anti_symmetrized_u
+        old_u = self._u
+        self._u = None
+        d_u = kernels.spin_expand_two_body(_stage(old_u), antisymmetrize=anti_now, out_dtype=c128)
+        del old_u
+
+        self.h = _deliver(d_h, np)
+        self.s = _deliver(d_s, np)
+        self.u = _deliver(d_u, np)
+        del d_u
+
+        if getattr(self, "u_repr", "4d") != "2d":
+            av = numpy.asarray(to_host(a)).astype(numpy.complex128).reshape(-1, 1)
+            bv = numpy.asarray(to_host(b)).astype(numpy.complex128).reshape(-1, 1)
+            assert abs(numpy.dot(av.conj().T, av) - 1) < 1e-12
+            assert abs(numpy.dot(bv.conj().T, bv) - 1) < 1e-12
+            assert abs(numpy.dot(av.conj().T, bv)) < 1e-12
+            self.a, self.b = convert(av, np), convert(bv, np)
+            sig = self.setup_pauli_matrices(av, bv, numpy)
+            self.sigma_x, self.sigma_y, self.sigma_z = (convert(m, np) for m in sig)
+            d_ov = d_overlap.to(c128)
+            stack = torch.stack(
+                [0.5 * torch.kron(d_ov, torch.from_numpy(m).to(d_ov.device)) for m in sig]
+            )
+            self.spin_x, self.spin_y, self.spin_z = (_deliver(stack[k], np) for k in range(3))
+            spin_2 = None
+            for k in range(3):
+                term = kernels.matmul(stack[k], kernels.matmul(d_s, stack[k]))
+                spin_2 = term if spin_2 is None else spin_2 + term
+            self.spin_2 = _deliver(spin_2, np)
+            # (2l)^4 complex: built on first access, see the property
+            self._spin_2_tb = None
+            self._spin_2_tb_recipe = (_deliver(stack, np), anti_now)
+
+        if anti_symmetrize:
+            self._anti_symmetrized_u = True
+
+        if self.position is not None:
+            self.position = _deliver(
+                kernels.add_spin_one_body(_stage(self.position), out_dtype=c128), np)
+        if self.momentum is not None:
+            self.momentum = _deliver(
+                kernels.add_spin_one_body(_stage(self.momentum), out_dtype=c128), np)
+        if self.spf is not None:
+            had_bra = self._bra_spf is not None
+            old_bra = self._bra_spf
+            self.spf = self.add_spin_spf(self.spf, np)
+            if had_bra:
+                self.bra_spf = self.add_spin_bra_spf(old_bra, np)
+        self.cast_to_complex()
+        return self
+
+    @staticmethod
+    def check_axis_lengths(arr, length):
+        return [length == axis for axis in arr.shape]

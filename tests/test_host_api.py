@@ -1,0 +1,193 @@
+"""CPU-only tests of the host-side mirror of the reference API: construction,
+shape-checking setters, sizes, module plumbing, deep copies, error behaviour.
+Nothing here computes a transform (that needs the GPU and is covered by
+``-m gpu`` tests); restated from the reference's tests where one exists."""
+
+import warnings
+
+import numpy as np
+import pytest
+
+import quantum_systems_amd as qsa
+from quantum_systems_amd import (
+    BasisSet, GeneralOrbitalSystem, RandomBasisSet, SpatialOrbitalSystem,
+    construct_custom_system, setup_basis_set,
+)
+from quantum_systems_amd.system_helper import compute_particle_density, delta, spin_delta
+
+
+def test_alias_package_is_the_hyphenated_one():
+    import importlib
+
+    real = importlib.import_module("quantum-systems_amd")
+    assert qsa is real
+    assert qsa.kernels is importlib.import_module("quantum-systems_amd.kernels")
+    from quantum_systems_amd.basis_set import BasisSet as B2
+
+    assert B2 is BasisSet
+
+
+def test_random_basis_reproduces_reference_stream(golden):
+    # draw order h, s, u, position, nuclear repulsion, charge (random_basis.py:21-35)
+    g = golden("random_basis_seed1234_l4_dim3")
+    np.random.seed(1234)
+    rbs = RandomBasisSet(4, 3)
+    for k in ("h", "s", "u", "position"):
+        assert np.array_equal(getattr(rbs, k), g[k])
+    assert rbs.nuclear_repulsion_energy == float(g["nuclear_repulsion_energy"])
+    assert rbs.charge == int(g["charge"])
+    assert rbs.u.dtype == np.complex128
+    assert rbs.dipole_moment.shape == (3, 4, 4)
+    np.testing.assert_allclose(rbs.u, rbs.u.transpose(1, 0, 3, 2))
+    np.testing.assert_allclose(rbs.h, rbs.h.conj().T)
+
+
+def test_spin_delta_law():
+    # reference tests/test_helper.py:6-11
+    for p in range(100):
+        for q in range(100):
+            assert spin_delta(p, q) == ((p % 2) == (q % 2))
+    assert delta(3, 3) and not delta(3, 4)
+
+
+def test_setters_check_every_axis():
+    bs = BasisSet(4, dim=2)
+    assert bs.np is np and bs.h is None and bs.particle_charge == -1
+    bs.h = np.zeros((4, 4))
+    with pytest.raises(AssertionError):
+        bs.h = np.zeros((4, 5))
+    with pytest.raises(AssertionError):
+        bs.u = np.zeros((4, 4, 4, 3))
+    with pytest.raises(AssertionError):
+        bs.position = np.zeros((3, 4, 4))      # dim is 2
+    with pytest.raises(AssertionError):
+        bs.position = np.zeros((2, 4, 3))
+    bs.position = np.zeros((2, 4, 4))
+    with pytest.raises(AssertionError):
+        bs.spin_x = np.zeros((4, 4))           # no spin in this basis
+    with pytest.raises(AssertionError):
+        bs.spf = np.zeros((5, 7, 7))
+    with pytest.raises(AssertionError):
+        bs.spf = np.zeros((4, 7))              # grid rank must equal dim
+    bs.spf = np.ones((4, 7, 7)) * (1 + 2j)
+    assert np.array_equal(bs.bra_spf, bs.spf.conj())   # lazy Hermitian dual
+    assert bs.check_axis_lengths(np.zeros((4, 4, 3)), 4) == [True, True, False]
+
+
+def test_system_sizes_and_assertions():
+    np.random.seed(0)
+    rbs = RandomBasisSet(10, 2)
+    spas = SpatialOrbitalSystem(4, rbs)
+    assert (spas.n, spas.l, spas.m) == (2, 10, 8)
+    assert spas.o == slice(0, 2) and spas.v == slice(2, 10)
+    assert spas.h is rbs.h and spas.u is rbs.u and spas.dim == 2
+    with pytest.raises(AssertionError):
+        SpatialOrbitalSystem(3, rbs)                     # odd particle number
+    with pytest.raises(AssertionError):
+        SpatialOrbitalSystem(22, rbs)                    # n // 2 > l
+    spin_basis = BasisSet(4, 1, includes_spin=True)
+    with pytest.raises(AssertionError):
+        SpatialOrbitalSystem(2, spin_basis)
+    with pytest.raises(NotImplementedError):
+        spas.change_to_hf_basis()
+    spas.set_system_size(3, 12)
+    assert (spas.m, spas.v) == (9, slice(3, 12))
+
+
+def test_double_spin_doubling_warns_and_returns_none():
+    # basis_set.py:561-566
+    bs = BasisSet(4, 1, includes_spin=True)
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        assert bs.change_to_general_orbital_basis() is None
+    assert any("already been spin-doubled" in str(x.message) for x in w)
+    assert bs.l == 4
+
+
+def test_copy_system_is_independent():
+    # reference tests/test_copy.py:6-18
+    np.random.seed(1)
+    spas = SpatialOrbitalSystem(2, RandomBasisSet(6, 2))
+    other = spas.copy_system()
+    assert other.np is np and other._basis_set.np is np and spas.np is np
+    assert other._basis_set is not spas._basis_set
+    for k in ("h", "u", "s", "position"):
+        assert np.array_equal(getattr(other, k), getattr(spas, k))
+        assert getattr(other, k) is not getattr(spas, k)
+    other.h[0, 0] = 123.0
+    assert spas.h[0, 0] != 123.0
+    basis_copy = spas._basis_set.copy_basis()
+    assert basis_copy.np is np and basis_copy.u is not spas.u
+
+
+def test_change_module_numpy_round_trip_keeps_values():
+    np.random.seed(2)
+    spas = SpatialOrbitalSystem(2, RandomBasisSet(5, 2))
+    before = spas.u.copy()
+    spas.change_module(np)
+    assert spas.np is np and spas._basis_set.np is np
+    assert isinstance(spas.u, np.ndarray) and np.array_equal(spas.u, before)
+    assert spas._basis_set.spf is None and spas._basis_set.momentum is None
+
+
+def test_setup_basis_set_and_unknown_system_type():
+    l = 4
+    h, s, u = np.eye(l), np.eye(l), np.zeros((l,) * 4)
+    bs = setup_basis_set(2, l, s, h, u, dim=2, particle_charge=+1,
+                         position=np.zeros((2, l, l)), nuclear_repulsion_energy=1.5)
+    assert bs.particle_charge == 1 and bs.nuclear_repulsion_energy == 1.5
+    assert bs.position.shape == (2, l, l) and bs.momentum is None
+    with pytest.raises(NotImplementedError):
+        construct_custom_system(2, l, s, h, u, system_type="banana")
+    sys_ = construct_custom_system(2, l, s, h, u, system_type="spatial")
+    assert isinstance(sys_, SpatialOrbitalSystem) and sys_.n == 1
+
+
+def test_compute_particle_density_matches_double_loop():
+    rng = np.random.default_rng(3)
+    l = 4
+    ket = rng.random((l, 5, 3)) + 1j * rng.random((l, 5, 3))
+    bra = rng.random((l, 5, 3)) + 1j * rng.random((l, 5, 3))
+    rho_qp = rng.random((l, l)) + 1j * rng.random((l, l))
+    ref = np.zeros((5, 3), dtype=complex)
+    for p in range(l):           # system_helper.py:20-25
+        for q in range(l):
+            ref += bra[p] * rho_qp[q, p] * ket[q]
+    np.testing.assert_allclose(compute_particle_density(rho_qp, ket, bra, np), ref, rtol=1e-13)
+
+
+def test_pauli_matrices_default_and_rotated_spinors(golden):
+    a = np.array([1, 0]).reshape(-1, 1)
+    b = np.array([0, 1]).reshape(-1, 1)
+    sx, sy, sz = BasisSet.setup_pauli_matrices(a, b, np)
+    assert np.array_equal(sx, [[0, 1], [1, 0]])
+    assert np.array_equal(sy, [[0, -1j], [1j, 0]])
+    assert np.array_equal(sz, [[1, 0], [0, -1]])
+    g = golden("gos_l4_custom_spinors_no_as")
+    got = BasisSet.setup_pauli_matrices(g["a"], g["b"], np)
+    for m, k in zip(got, ("gos_sigma_x", "gos_sigma_y", "gos_sigma_z")):
+        np.testing.assert_allclose(m, g[k], atol=1e-15)
+
+
+def test_transforms_need_a_gpu_and_say_so():
+    import torch
+
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    np.random.seed(4)
+    spas = SpatialOrbitalSystem(2, RandomBasisSet(4, 1))
+    with pytest.raises(RuntimeError, match="GPU"):
+        spas.change_basis(np.eye(4))
+    with pytest.raises(RuntimeError, match="GPU"):
+        spas.construct_general_orbital_system()
+    with pytest.raises(RuntimeError, match="GPU"):
+        BasisSet.anti_symmetrize_u(np.zeros((2, 2, 2, 2)))
+
+
+def test_general_system_requires_n_le_l():
+    bs = BasisSet(2, 1, includes_spin=True, anti_symmetrized_u=True)
+    bs.h, bs.s, bs.u = np.eye(2), np.eye(2), np.zeros((2,) * 4)
+    gos = GeneralOrbitalSystem(2, bs)        # already spin + anti-symmetric: no compute
+    assert gos.n == 2 and gos.m == 0
+    with pytest.raises(AssertionError):
+        GeneralOrbitalSystem(3, bs)
