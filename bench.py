@@ -40,7 +40,7 @@ def parse():
     ap.add_argument("--layout", choices=["replicated", "sharded"], default="replicated")
     ap.add_argument("--gather", action="store_true", help="include the all-gather of the result")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-l", type=int, default=96, help="size of the CPU-baseline sample")
+    ap.add_argument("--cpu-l", type=int, default=176, help="largest size of the CPU-baseline sample")
     ap.add_argument("--no-probes", action="store_true")
     return ap.parse_args()
 
@@ -90,9 +90,11 @@ def identity_check(torch, u, out_rows, C, Ct, p_lo, seed=7):
     return lhs, rhs
 
 
-def cpu_baseline(l):
+def cpu_baseline(l_max, budget_s=15.0):
     """The oracle (NumPy restatement of basis_set.py:341-348) timed on the
-    host cores of this box on a bounded sample of the same workload."""
+    host cores of this box on a bounded sample of the same workload: a pilot
+    at l=48 sizes the sample so that it takes roughly `budget_s` seconds
+    (time ~ l^5), capped at l_max."""
     import numpy as np
 
     from oracle import qs_oracle as orc
@@ -105,19 +107,28 @@ def cpu_baseline(l):
         blas = ",".join(sorted({str(i.get("internal_api")) for i in infos})) or "unknown"
     except Exception:
         threads, blas = os.cpu_count() or 1, "unknown"
-    rng = np.random.default_rng(0)
-    u = rng.random((l, l, l, l))
-    u = 0.5 * (u + u.transpose(1, 0, 3, 2))
-    C, _ = np.linalg.qr(rng.standard_normal((l, l)))
-    t0 = time.perf_counter()
-    out = orc.transform_two_body(u, C)
-    dt = time.perf_counter() - t0
-    assert out.shape == (l, l, l, l)
+
+    def run(l):
+        rng = np.random.default_rng(0)
+        u = rng.random((l, l, l, l))
+        u = 0.5 * (u + u.transpose(1, 0, 3, 2))
+        C, _ = np.linalg.qr(rng.standard_normal((l, l)))
+        t0 = time.perf_counter()
+        out = orc.transform_two_body(u, C)
+        dt = time.perf_counter() - t0
+        assert out.shape == (l, l, l, l)
+        return dt
+
+    run(32)                                   # BLAS thread pool warm-up
+    pilot = run(48)
+    l = int(min(l_max, max(48, 48 * (budget_s / max(pilot, 1e-3)) ** 0.2)))
+    l -= l % 8
+    dt = run(l)
     flops = orc.transform_flops(l, l)
     return {
         "value": flops / dt / 1e12, "unit": "TFLOP/s", "cores": int(threads), "kind": "port",
         "sample": f"one fp64 transform at l={l} ({flops/1e9:.1f} GFLOP, {dt:.1f} s), numpy "
-                  f"{np.__version__} tensordot x4 on {blas} with {threads} threads "
+                  f"{np.__version__} tensordot x4 (oracle/qs_oracle.py) on {blas} with {threads} threads "
                   f"(os.cpu_count={os.cpu_count()})",
     }
 
@@ -253,8 +264,8 @@ def main():
     probes = {}
     if not args.no_probes:
         st = torch.cuda.current_stream().cuda_stream
-        sink = torch.zeros(8, dtype=torch.float64, device=device)
         blocks, iters = 256 * 8, 4000
+        sink = torch.zeros(1 + 2 * blocks, dtype=torch.int64, device=device)
         lib.qs_probe_mfma_f64(sink.data_ptr(), blocks, iters, st)
         torch.cuda.synchronize()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -263,6 +274,18 @@ def main():
         e1.record()
         torch.cuda.synchronize()
         probes["mfma_f64_register_loop_tflops"] = blocks * 4 * iters * 8 * 2048 / (e0.elapsed_time(e1) * 1e-3) / 1e12
+        stamps = sink[1:].reshape(blocks, 2).to(torch.float64)
+        probes["mfma_f64_register_loop_clock_ghz"] = (stamps[:, 0] / stamps[:, 1]).median().item() * 0.1
+        nbytes = 1 << 30
+        src = torch.empty(nbytes, dtype=torch.uint8, device=device)
+        dst = torch.empty(nbytes, dtype=torch.uint8, device=device)
+        lib.qs_probe_stream_copy(src.data_ptr(), dst.data_ptr(), nbytes, st)
+        e0.record()
+        lib.qs_probe_stream_copy(src.data_ptr(), dst.data_ptr(), nbytes, st)
+        e1.record()
+        torch.cuda.synchronize()
+        probes["hbm_stream_copy_tbps"] = 2 * nbytes / (e0.elapsed_time(e1) * 1e-3) / 1e12
+        del src, dst
 
     line = {
         "metric": f"4-index u transform TFLOP/s ({'fp64' if kf == 1 else 'complex128'}) at L={l} orbitals",

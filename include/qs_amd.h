@@ -170,7 +170,10 @@ int qs_spin_squared_two_body(const void* S, void* out, int64_t n, int64_t p_lo,
  *     "gemm_f64_cfg", "gemm_c128_cfg" (0 = automatic).
  *   qs_probe_mfma_f64: register-resident fp64 MFMA loop, `blocks` workgroups
  *     of 4 waves, each wave issuing iters*8 v_mfma_f64_16x16x4_f64
- *     (flops = blocks*4*iters*8*2048); `sink` is an 8-byte device scratch.
+ *     (flops = blocks*4*iters*8*2048); `sink` is a device scratch of
+ *     8 + 16*blocks bytes: after the dummy first word, per block the deltas of
+ *     the shader clock and of the 100 MHz counter around the loop (their ratio
+ *     x 100 MHz is the clock the chip holds under pure MFMA load).
  *   qs_probe_stream_copy: 16-byte-per-lane device copy (moves 2*bytes).
  * bench.py uses the probes to print measured ceilings beside datasheet ones.
  */

@@ -291,16 +291,43 @@ static bool fill_args(GemmArgs& g, const double* A, const double* B, double* C, 
     return true;
 }
 
+// ---------------------------------------------------------------------------
+// Tile-shape choice.  All shapes are 4-wave workgroups (two resident per CU)
+// except the two 8-wave ones kept for tuning.  The automatic choice minimises
+// padded work  tiles_m*BM * tiles_n*BN / weight  over the candidate list; the
+// weights are the measured relative rates of the shapes on full tiles
+// (MI355X, l=256 / l=128: profiles/r01_tile_sweep.txt).
+// ---------------------------------------------------------------------------
+struct TileShape { int id, bm, bn; double weight; };
+
+static int pick_shape(const TileShape* cand, int ncand, int64_t m, int64_t n) {
+    int best = cand[0].id;
+    double best_cost = 1e300;
+    for (int i = 0; i < ncand; ++i) {
+        const double padded = (double)(cdiv(m, cand[i].bm) * cand[i].bm) *
+                              (double)(cdiv(n, cand[i].bn) * cand[i].bn);
+        const double cost = padded / cand[i].weight;
+        if (cost < best_cost) { best_cost = cost; best = cand[i].id; }
+    }
+    return best;
+}
+
 template <int MODE>
 static int dispatch_f64(int cfg, const GemmArgs& g, int64_t batch, hipStream_t s) {
     switch (cfg) {
-        case 1: return launch_one<2, 2, 4, 4, 16, MODE>(g, batch, s);   // 128 x 128, 2 WG/CU
-        case 2: return launch_one<4, 1, 4, 4, 16, MODE>(g, batch, s);   // 256 x  64
-        case 3: return launch_one<1, 4, 4, 4, 16, MODE>(g, batch, s);   //  64 x 256
-        case 4: return launch_one<1, 4, 2, 4, 16, MODE>(g, batch, s);   //  32 x 256 (short slabs)
-        case 5: return launch_one<2, 2, 2, 2, 16, MODE>(g, batch, s);   //  64 x  64, 4 waves
-        case 6: return launch_one<4, 2, 4, 4, 16, MODE>(g, batch, s);   // 256 x 128, 8 waves
-        case 7: return launch_one<2, 4, 4, 4, 16, MODE>(g, batch, s);   // 128 x 256, 8 waves
+        case 1: return launch_one<2, 2, 4, 4, 16, MODE>(g, batch, s);    // 128 x 128
+        case 2: return launch_one<4, 1, 4, 4, 16, MODE>(g, batch, s);    // 256 x  64 (1 WG/CU)
+        case 3: return launch_one<1, 4, 4, 4, 16, MODE>(g, batch, s);    //  64 x 256 (1 WG/CU)
+        case 4: return launch_one<1, 4, 2, 4, 16, MODE>(g, batch, s);    //  32 x 256
+        case 5: return launch_one<2, 2, 2, 2, 16, MODE>(g, batch, s);    //  64 x  64
+        case 6: return launch_one<4, 2, 4, 4, 16, MODE>(g, batch, s);    // 256 x 128, 8 waves
+        case 7: return launch_one<2, 4, 4, 4, 16, MODE>(g, batch, s);    // 128 x 256, 8 waves
+        case 8: return launch_one<2, 2, 3, 3, 16, MODE>(g, batch, s);    //  96 x  96
+        case 9: return launch_one<2, 2, 4, 2, 16, MODE>(g, batch, s);    // 128 x  64
+        case 10: return launch_one<2, 2, 2, 4, 16, MODE>(g, batch, s);   //  64 x 128
+        case 11: return launch_one<2, 2, 1, 1, 16, MODE>(g, batch, s);   //  32 x  32
+        case 12: return launch_one<2, 2, 3, 4, 16, MODE>(g, batch, s);   //  96 x 128
+        case 13: return launch_one<2, 2, 4, 3, 16, MODE>(g, batch, s);   // 128 x  96
         default: return QS_ERR_BAD_EXTENT;
     }
 }
@@ -316,10 +343,11 @@ int gemm_f64(const double* A, const double* B, double* C, int64_t m, int64_t n, 
                      !(n & 1) && !(sa & 1) && !(sb & 1);
     int cfg = g_gemm_f64_cfg;
     if (cfg == 0) {
-        if (m <= 64 && n <= 64) cfg = 5;
-        else if (n <= 64) cfg = 2;
-        else if (m <= 64) cfg = 3;
-        else cfg = 1;
+        static const TileShape cand[] = {
+            {1, 128, 128, 1.00}, {12, 96, 128, 0.97}, {13, 128, 96, 0.97}, {8, 96, 96, 0.96},
+            {9, 128, 64, 0.95},  {10, 64, 128, 0.95}, {5, 64, 64, 0.93},   {11, 32, 32, 0.60},
+        };
+        cfg = pick_shape(cand, sizeof(cand) / sizeof(cand[0]), m, n);
     }
     return vec ? dispatch_f64<MODE_F64_VEC2>(cfg, g, batch, stream)
                : dispatch_f64<MODE_F64_SCALAR>(cfg, g, batch, stream);
@@ -333,9 +361,11 @@ int gemm_c128(const double* A, const double* B, double* C, int64_t m, int64_t n,
         return QS_ERR_BAD_EXTENT;
     int cfg = g_gemm_c128_cfg;
     if (cfg == 0) {
-        if (m <= 32 && n <= 32) cfg = 4;
-        else if (m >= n) cfg = 2;
-        else cfg = 1;
+        static const TileShape cand[] = {
+            {1, 64, 128, 1.00}, {2, 128, 64, 1.00}, {7, 96, 64, 0.97}, {8, 64, 96, 0.97},
+            {6, 64, 64, 0.95},  {4, 32, 32, 0.62},
+        };
+        cfg = pick_shape(cand, sizeof(cand) / sizeof(cand[0]), m, n);
     }
     switch (cfg) {
         case 1: return launch_one<2, 2, 2, 4, 8, MODE_C128>(g, batch, stream);   //  64 x 128
@@ -343,6 +373,10 @@ int gemm_c128(const double* A, const double* B, double* C, int64_t m, int64_t n,
         case 3: return launch_one<4, 1, 2, 4, 8, MODE_C128>(g, batch, stream);   // 128 x  64 (tall waves)
         case 4: return launch_one<2, 2, 1, 1, 8, MODE_C128>(g, batch, stream);   //  32 x  32
         case 5: return launch_one<1, 4, 2, 4, 8, MODE_C128>(g, batch, stream);   //  32 x 256
+        case 6: return launch_one<2, 2, 2, 2, 8, MODE_C128>(g, batch, stream);   //  64 x  64
+        case 7: return launch_one<2, 2, 3, 2, 8, MODE_C128>(g, batch, stream);   //  96 x  64
+        case 8: return launch_one<2, 2, 2, 3, 8, MODE_C128>(g, batch, stream);   //  64 x  96
+        case 9: return launch_one<2, 2, 3, 3, 8, MODE_C128>(g, batch, stream);   //  96 x  96
         default: return QS_ERR_BAD_EXTENT;
     }
 }

@@ -10,21 +10,41 @@ namespace qs {
 typedef double f64x4 __attribute__((ext_vector_type(4)));
 typedef double f64x2 __attribute__((ext_vector_type(2)));
 
-// 8 independent accumulators per wave, operands in registers, no memory traffic.
+// 8 independent accumulators per wave, operands in registers, no memory
+// traffic.  The MFMAs are inline asm so the loop body is exactly 8 MFMAs (the
+// compiler otherwise shuffles the loop-carried accumulators between the two
+// register-file halves every iteration).  Lane 0 of wave 0 stores the shader
+// clock and the 100 MHz real-time counter deltas around the loop: the clock
+// the chip holds under this load is dt_shader / dt_real * 100 MHz.
 __global__ __launch_bounds__(256) void mfma_f64_probe_kernel(double* sink, int iters, double seed) {
-    f64x4 acc[8];
-#pragma unroll
-    for (int i = 0; i < 8; ++i) acc[i] = f64x4{0.0, 0.0, 0.0, 0.0};
-    const double a = seed + 1e-9 * threadIdx.x, b = 1.0 - 1e-9 * threadIdx.x;
+    f64x4 c0 = {0, 0, 0, 0}, c1 = c0, c2 = c0, c3 = c0, c4 = c0, c5 = c0, c6 = c0, c7 = c0;
+    const double a = seed + 1e-3 * threadIdx.x, b = 1.0 - 1e-3 * threadIdx.x;
+    const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+    const unsigned long long r0 = __builtin_amdgcn_s_memrealtime();
     for (int it = 0; it < iters; ++it) {
-#pragma unroll
-        for (int i = 0; i < 8; ++i)
-            acc[i] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc[i], 0, 0, 0);
+        asm volatile(
+            "v_mfma_f64_16x16x4_f64 %0, %8, %9, %0\n\t"
+            "v_mfma_f64_16x16x4_f64 %1, %8, %9, %1\n\t"
+            "v_mfma_f64_16x16x4_f64 %2, %8, %9, %2\n\t"
+            "v_mfma_f64_16x16x4_f64 %3, %8, %9, %3\n\t"
+            "v_mfma_f64_16x16x4_f64 %4, %8, %9, %4\n\t"
+            "v_mfma_f64_16x16x4_f64 %5, %8, %9, %5\n\t"
+            "v_mfma_f64_16x16x4_f64 %6, %8, %9, %6\n\t"
+            "v_mfma_f64_16x16x4_f64 %7, %8, %9, %7\n\t"
+            : "+v"(c0), "+v"(c1), "+v"(c2), "+v"(c3), "+v"(c4), "+v"(c5), "+v"(c6), "+v"(c7)
+            : "v"(a), "v"(b));
     }
+    asm volatile("s_nop 15\n\ts_nop 15\n\ts_nop 15" ::: "memory");   // MFMA result -> VALU read hazard
+    const unsigned long long t1 = __builtin_amdgcn_s_memtime();
+    const unsigned long long r1 = __builtin_amdgcn_s_memrealtime();
     double r = 0.0;
-#pragma unroll
-    for (int i = 0; i < 8; ++i) r += acc[i][0] + acc[i][1] + acc[i][2] + acc[i][3];
-    if (r == 12345.6789) sink[0] = r;   // keep the chain alive, never true in practice
+    r += c0[0] + c1[1] + c2[2] + c3[3] + c4[0] + c5[1] + c6[2] + c7[3];
+    if (r == 12345.6789) sink[0] = r;   // keeps the chains alive, never true in practice
+    if (threadIdx.x == 0) {
+        unsigned long long* st = reinterpret_cast<unsigned long long*>(sink) + 1 + 2 * (size_t)blockIdx.x;
+        st[0] = t1 - t0;
+        st[1] = r1 - r0;
+    }
 }
 
 __global__ __launch_bounds__(256) void stream_copy_kernel(const f64x2* __restrict__ src,
@@ -41,7 +61,8 @@ using namespace qs;
 extern "C" {
 
 // Launch `blocks` workgroups of 4 waves, each wave issuing iters*8 MFMAs.
-// flops = blocks * 4 * iters * 8 * 2048.
+// flops = blocks * 4 * iters * 8 * 2048.  `sink` holds 8 + 16*blocks bytes:
+// word 0 is a dummy result, then per block {shader-clock delta, 100 MHz delta}.
 int qs_probe_mfma_f64(void* sink, int64_t blocks, int64_t iters, void* stream) {
     if (!sink) return QS_ERR_NULL_POINTER;
     if (blocks <= 0 || iters <= 0 || blocks > (1 << 20) || iters > (1 << 24)) return QS_ERR_BAD_EXTENT;

@@ -37,8 +37,8 @@ def timeit(fn, reps=5, warm=2):
 
 
 def probe():
-    sink = torch.zeros(8, dtype=torch.float64, device=dev)
     blocks, iters = 256 * 8, 4000
+    sink = torch.zeros(1 + 2 * blocks, dtype=torch.int64, device=dev)
     st = torch.cuda.current_stream().cuda_stream
     med, best = timeit(lambda: lib.qs_probe_mfma_f64(sink.data_ptr(), blocks, iters, st))
     fl = blocks * 4 * iters * 8 * 2048
