@@ -42,6 +42,11 @@ int gemm_c128(const double* A, const double* B, double* C, int64_t m, int64_t n,
               int64_t k, int64_t lda, int64_t ldb, int64_t ldc, int64_t batch,
               int64_t sa, int64_t sb, int64_t sc, int accumulate, hipStream_t stream);
 
+// Exact-tiling fast path (qs_gemm_fast.hip): QS_OK / error after launching, 1 = not eligible.
+int gemm_fast_try(int dtype, const double* A, const double* B, double* C, int64_t m, int64_t n,
+                  int64_t k, int64_t lda, int64_t ldb, int64_t ldc, int64_t batch, int64_t sa,
+                  int64_t sb, int64_t sc, int accumulate, int group_along_m, hipStream_t stream);
+
 // out (cols, rows) = in (rows, cols)^T, element = 8 or 16 bytes (tiny helper
 // for the coefficient matrices).
 int transpose_small(int dtype, const void* in, void* out, int64_t rows,
@@ -59,5 +64,8 @@ int spin2_two_body(const void* S, void* out, int64_t n, int64_t p_lo, int64_t p_
 // Tuning knobs (qs_tuning_set).
 extern int g_gemm_f64_cfg;
 extern int g_gemm_c128_cfg;
+extern int g_gemm_pipe;
+extern int g_gemm_debug;
+extern int g_gemm_fast;
 
 }  // namespace qs

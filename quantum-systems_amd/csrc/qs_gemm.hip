@@ -54,6 +54,7 @@ struct GemmArgs {
     int tiles_m, tiles_n;
     int group_along_m;   // 1: tiles that share a B panel (same n-tile) are adjacent
     int accumulate;      // 1: C += A.B (C is read in the epilogue), 0: C = A.B
+    int debug;           // DIAGNOSTIC ONLY (qs_tuning_set "gemm_debug"): bit0 skip epilogue stores
 };
 
 // Work index of a workgroup: XCD x gets the x-th contiguous chunk of the work
@@ -66,7 +67,7 @@ __device__ __forceinline__ unsigned xcd_chunked_index(unsigned bid, unsigned nwg
     return base + slot;
 }
 
-template <int WM, int WN, int TM, int TN, int KT, int MODE>
+template <int WM, int WN, int TM, int TN, int KT, int MODE, bool PIPE>
 __global__ __launch_bounds__(64 * WM * WN, (WM * WN <= 4) ? 2 : 1)
 void gemm_kernel(const GemmArgs g) {
     constexpr bool CX = (MODE == MODE_C128);
@@ -78,7 +79,7 @@ void gemm_kernel(const GemmArgs g) {
     constexpr int BN = 16 * TN * WN;
     constexpr int SA = KT + 2;                // (SA/2) odd -> 16 rows hit 16 distinct bank pairs
     constexpr int SB = BN + 16;               // consecutive k rows land 16 bank pairs apart
-    static_assert(KT == 8 || KT == 16, "KT");
+    static_assert(KT == 8 || KT == 16, "KT");   // KT/4 k-steps per stage, must be even
     // staging: one item = 16 bytes (f64x2 or one complex) except scalar mode (8 bytes)
     constexpr int IPR_A = SCALAR ? KT : (CX ? KT : KT / 2);   // items per A row
     constexpr int IPR_B = SCALAR ? BN : (CX ? BN : BN / 2);   // items per B row
@@ -117,6 +118,11 @@ void gemm_kernel(const GemmArgs g) {
     typedef typename std::conditional<SCALAR, double, f64x2>::type item_t;
     item_t ra[NA], rb[NB];
 
+    // Branch-free staging.  fetch() only issues loads: an out-of-range item
+    // reads element 0 of its operand (always valid memory).  stash() zeroes those
+    // items and writes the stage to LDS; it sits behind a scheduling fence so
+    // that neither the zeroing selects nor the wait for the loads can drift up
+    // in front of the MFMAs that are meant to cover the load latency.
     auto fetch = [&](int k0) {
 #pragma unroll
         for (int i = 0; i < NA; ++i) {
@@ -125,9 +131,9 @@ void gemm_kernel(const GemmArgs g) {
             const int kc = (c % IPR_A) * ((SCALAR || CX) ? 1 : 2);
             const int gr = m0 + row, gk = k0 + kc;
             const bool ok = gr < M && gk < K;
-            const double* p = A + ((int64_t)gr * g.lda + gk) * ES;
-            if constexpr (SCALAR) ra[i] = ok ? *p : 0.0;
-            else ra[i] = ok ? *reinterpret_cast<const f64x2*>(p) : f64x2{0.0, 0.0};
+            const double* p = A + (ok ? ((int64_t)gr * g.lda + gk) * ES : 0);
+            if constexpr (SCALAR) ra[i] = *p;
+            else ra[i] = *reinterpret_cast<const f64x2*>(p);
         }
 #pragma unroll
         for (int i = 0; i < NB; ++i) {
@@ -136,13 +142,14 @@ void gemm_kernel(const GemmArgs g) {
             const int nc = (c % IPR_B) * ((SCALAR || CX) ? 1 : 2);
             const int gk = k0 + row, gn = n0 + nc;
             const bool ok = gk < K && gn < N;
-            const double* p = B + ((int64_t)gk * g.ldb + gn) * ES;
-            if constexpr (SCALAR) rb[i] = ok ? *p : 0.0;
-            else rb[i] = ok ? *reinterpret_cast<const f64x2*>(p) : f64x2{0.0, 0.0};
+            const double* p = B + (ok ? ((int64_t)gk * g.ldb + gn) * ES : 0);
+            if constexpr (SCALAR) rb[i] = *p;
+            else rb[i] = *reinterpret_cast<const f64x2*>(p);
         }
     };
 
-    auto stash = [&](int buf) {
+    auto stash = [&](int buf, int k0) {
+        __builtin_amdgcn_sched_barrier(0);
         double* as = As + buf * A_STAGE;
         double* bs = Bs + buf * B_STAGE;
 #pragma unroll
@@ -150,20 +157,28 @@ void gemm_kernel(const GemmArgs g) {
             const int c = tid + i * NT;
             const int row = c / IPR_A;
             const int kc = (c % IPR_A) * ((SCALAR || CX) ? 1 : 2);
+            const bool ok = (m0 + row) < M && (k0 + kc) < K;
             double* d = as + row * SA + kc;
-            if constexpr (SCALAR) *d = ra[i];
-            else if constexpr (CX) { d[0] = ra[i][0]; d[BM * SA] = ra[i][1]; }
-            else *reinterpret_cast<f64x2*>(d) = ra[i];
+            if constexpr (SCALAR) *d = ok ? ra[i] : 0.0;
+            else {
+                const f64x2 v = ok ? ra[i] : f64x2{0.0, 0.0};
+                if constexpr (CX) { d[0] = v[0]; d[BM * SA] = v[1]; }
+                else *reinterpret_cast<f64x2*>(d) = v;
+            }
         }
 #pragma unroll
         for (int i = 0; i < NB; ++i) {
             const int c = tid + i * NT;
             const int row = c / IPR_B;
             const int nc = (c % IPR_B) * ((SCALAR || CX) ? 1 : 2);
+            const bool ok = (k0 + row) < K && (n0 + nc) < N;
             double* d = bs + row * SB + nc;
-            if constexpr (SCALAR) *d = rb[i];
-            else if constexpr (CX) { d[0] = rb[i][0]; d[KT * SB] = rb[i][1]; }
-            else *reinterpret_cast<f64x2*>(d) = rb[i];
+            if constexpr (SCALAR) *d = ok ? rb[i] : 0.0;
+            else {
+                const f64x2 v = ok ? rb[i] : f64x2{0.0, 0.0};
+                if constexpr (CX) { d[0] = v[0]; d[KT * SB] = v[1]; }
+                else *reinterpret_cast<f64x2*>(d) = v;
+            }
         }
     };
 
@@ -176,47 +191,111 @@ void gemm_kernel(const GemmArgs g) {
             for (int j = 0; j < TN; ++j) acc[p][i][j] = f64x4{0.0, 0.0, 0.0, 0.0};
 
     const int nk = (K + KT - 1) / KT;
-    fetch(0);
-    stash(0);
-    __syncthreads();
-
     const int a_off = (wm * 16 * TM + (lane & 15)) * SA + (lane >> 4);
     const int b_off = (lane >> 4) * SB + wn * 16 * TN + (lane & 15);
+    constexpr int KS = KT / 4;   // MFMA k-steps per stage
 
-    for (int t = 0; t < nk; ++t) {
-        const int cur = t & 1;
-        if (t + 1 < nk) fetch((t + 1) * KT);
-        const double* as = As + cur * A_STAGE + a_off;
-        const double* bs = Bs + cur * B_STAGE + b_off;
+    auto read_frags = [&](int buf, int kk, double (&af)[NP][TM], double (&bf)[NP][TN]) {
+        const double* as = As + buf * A_STAGE + a_off;
+        const double* bs = Bs + buf * B_STAGE + b_off;
 #pragma unroll
-        for (int kk = 0; kk < KT / 4; ++kk) {
-            double af[NP][TM], bf[NP][TN];
+        for (int p = 0; p < NP; ++p) {
 #pragma unroll
-            for (int p = 0; p < NP; ++p) {
+            for (int i = 0; i < TM; ++i) af[p][i] = as[p * BM * SA + i * 16 * SA + kk * 4];
 #pragma unroll
-                for (int i = 0; i < TM; ++i) af[p][i] = as[p * BM * SA + i * 16 * SA + kk * 4];
+            for (int j = 0; j < TN; ++j) bf[p][j] = bs[p * KT * SB + kk * 4 * SB + j * 16];
+        }
+    };
+    auto mfma_step = [&](const double (&af)[NP][TM], const double (&bf)[NP][TN]) {
 #pragma unroll
-                for (int j = 0; j < TN; ++j) bf[p][j] = bs[p * KT * SB + kk * 4 * SB + j * 16];
-            }
+        for (int i = 0; i < TM; ++i) {
 #pragma unroll
-            for (int i = 0; i < TM; ++i) {
-#pragma unroll
-                for (int j = 0; j < TN; ++j) {
-                    if constexpr (!CX) {
-                        acc[0][i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[0][i], bf[0][j], acc[0][i][j], 0, 0, 0);
-                    } else {
-                        acc[0][i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[0][i], bf[0][j], acc[0][i][j], 0, 0, 0);
-                        acc[1][i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[0][i], bf[1][j], acc[1][i][j], 0, 0, 0);
-                        acc[0][i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(-af[1][i], bf[1][j], acc[0][i][j], 0, 0, 0);
-                        acc[1][i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[1][i], bf[0][j], acc[1][i][j], 0, 0, 0);
-                    }
+            for (int j = 0; j < TN; ++j) {
+                if constexpr (!CX) {
+                    acc[0][i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[0][i], bf[0][j], acc[0][i][j], 0, 0, 0);
+                } else {
+                    acc[0][i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[0][i], bf[0][j], acc[0][i][j], 0, 0, 0);
+                    acc[1][i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[0][i], bf[1][j], acc[1][i][j], 0, 0, 0);
+                    acc[0][i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(-af[1][i], bf[1][j], acc[0][i][j], 0, 0, 0);
+                    acc[1][i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[1][i], bf[0][j], acc[1][i][j], 0, 0, 0);
                 }
             }
         }
-        if (t + 1 < nk) stash(cur ^ 1);
-        __syncthreads();
+    };
+
+    if (g.debug & 6) {   // DIAGNOSTIC: asymmetric wave priority between co-resident workgroups
+        unsigned hwid;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
+        const unsigned sel = (g.debug & 2) ? (blockIdx.x & 1u) : ((hwid >> 0) & 1u);   // bit1: block parity, bit2: wave-slot parity
+        if (__builtin_amdgcn_readfirstlane(sel)) __builtin_amdgcn_s_setprio(2);
+    }
+    fetch(0);
+    stash(0, 0);
+    __syncthreads();
+
+    if constexpr (!PIPE) {
+        // plain schedule: [fetch next] [all k-steps of this stage] [stash next] barrier
+        for (int t = 0; t < nk; ++t) {
+            const int cur = t & 1;
+            if (t + 1 < nk) fetch((t + 1) * KT);
+#pragma unroll
+            for (int kk = 0; kk < KS; ++kk) {
+                double af[NP][TM], bf[NP][TN];
+                read_frags(cur, kk, af, bf);
+                mfma_step(af, bf);
+            }
+            if (t + 1 < nk) stash(cur ^ 1, (t + 1) * KT);
+            __syncthreads();
+        }
+    } else {
+        // rotated schedule: the last k-step of every stage runs AFTER the stage
+        // barrier, from fragments read before it, while the first fragments of
+        // the next stage and the global loads of the stage after are in flight.
+        // The MFMA stream therefore continues across the barrier; a wave only
+        // loses issue time to barrier skew.  Fragments are double-buffered in
+        // registers (f0/f1), k-step kk+1 is read while kk multiplies.
+        double a0[NP][TM], b0[NP][TN], a1[NP][TM], b1[NP][TN];
+        if (nk > 1) fetch(KT);
+        read_frags(0, 0, a0, b0);
+        auto stage = [&](int t, auto do_stash, auto do_fetch, auto do_next) {
+            const int cur = t & 1;
+#pragma unroll
+            for (int kk = 0; kk + 1 < KS; ++kk) {
+                // the fence keeps the fragment reads of step kk+1 AHEAD of the
+                // MFMAs of step kk (the compiler otherwise sinks them behind the
+                // MFMA cluster and every k-step pays the LDS latency)
+                if ((kk & 1) == 0) { read_frags(cur, kk + 1, a1, b1); __builtin_amdgcn_sched_barrier(0); mfma_step(a0, b0); }
+                else               { read_frags(cur, kk + 1, a0, b0); __builtin_amdgcn_sched_barrier(0); mfma_step(a1, b1); }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            if constexpr (decltype(do_stash)::value) stash(cur ^ 1, (t + 1) * KT);
+            __syncthreads();
+            if constexpr (decltype(do_fetch)::value) fetch((t + 2) * KT);
+            // KS is even: the last k-step lives in (a1, b1); (a0, b0) is free again
+            if constexpr (decltype(do_next)::value) read_frags(cur ^ 1, 0, a0, b0);
+            __builtin_amdgcn_sched_barrier(0);
+            mfma_step(a1, b1);
+            __builtin_amdgcn_sched_barrier(0);
+        };
+        using T_ = std::true_type;
+        using F_ = std::false_type;
+        int t = 0;
+        for (; t + 2 < nk; ++t) stage(t, T_{}, T_{}, T_{});
+        if (t + 1 < nk) { stage(t, T_{}, F_{}, T_{}); ++t; }
+        stage(t, F_{}, F_{}, F_{});
     }
 
+    if (g.debug & 1) {   // DIAGNOSTIC bit0: timing experiment: no stores (keeps the accumulators alive)
+        double keep = 0.0;
+#pragma unroll
+        for (int p = 0; p < NP; ++p)
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) keep += acc[p][i][j][0] + acc[p][i][j][1] + acc[p][i][j][2] + acc[p][i][j][3];
+        if (keep == 1.2345e-300) C[0] = keep;
+        return;
+    }
     // epilogue: reg r of a lane -> row (lane>>4) + 4r, col lane&15 of each 16x16 block
     const int crow = m0 + wm * 16 * TM + (lane >> 4);
     const int ccol = n0 + wn * 16 * TN + (lane & 15);
@@ -248,6 +327,12 @@ void gemm_kernel(const GemmArgs g) {
     }
 }
 
+// Schedule / tile-shape overrides for tuning runs (qs_tuning_set); 0 = automatic.
+int g_gemm_f64_cfg = 0;
+int g_gemm_c128_cfg = 0;
+int g_gemm_debug = 0;    // diagnostic bits, see GemmArgs::debug
+int g_gemm_pipe = 1;     // 1: rotated K-loop schedule, 0: plain schedule (A/B reference)
+
 template <int WM, int WN, int TM, int TN, int KT, int MODE>
 static int launch_one(GemmArgs g, int64_t batch, hipStream_t stream) {
     constexpr int BM = 16 * TM * WM, BN = 16 * TN * WN;
@@ -257,21 +342,24 @@ static int launch_one(GemmArgs g, int64_t batch, hipStream_t stream) {
     const int64_t nwg = (int64_t)g.tiles_m * g.tiles_n * batch;
     if (nwg <= 0 || nwg >= (int64_t(1) << 31)) return QS_ERR_BAD_EXTENT;
     const size_t lds = sizeof(double) * 2 * NP * (BM * (KT + 2) + KT * (BN + 16));
-    auto kern = gemm_kernel<WM, WN, TM, TN, KT, MODE>;
-    static bool lds_opt_in = false;   // per instantiation; a repeated call is harmless
-    if (lds > 64 * 1024 && !lds_opt_in) {
+    static bool lds_opt_in[2] = {false, false};   // per instantiation; a repeated call is harmless
+    // the rotated schedule needs a second fragment set; shapes where that would
+    // spill (8-byte staging with 16 accumulators, the 96x96 complex tile, the
+    // 1-WG/CU tuning shapes) keep the plain schedule
+    constexpr bool pipe_fits = !((MODE == MODE_F64_SCALAR && TM * TN >= 16) ||
+                                 (MODE == MODE_C128 && TM * TN >= 9) || WM * WN != 4 || WM != WN);
+    const int pipe = (g_gemm_pipe && pipe_fits) ? 1 : 0;
+    auto kern = pipe ? gemm_kernel<WM, WN, TM, TN, KT, MODE, true>
+                     : gemm_kernel<WM, WN, TM, TN, KT, MODE, false>;
+    if (lds > 64 * 1024 && !lds_opt_in[pipe]) {
         hipError_t e = hipFuncSetAttribute((const void*)kern,
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return hip_status(e, "hipFuncSetAttribute(gemm)");
-        lds_opt_in = true;
+        lds_opt_in[pipe] = true;
     }
     hipLaunchKernelGGL(kern, dim3((unsigned)nwg), dim3(64 * WM * WN), lds, stream, g);
     return launch_status("gemm launch");
 }
-
-// Tile-shape overrides for tuning runs (qs_tuning_set); 0 = automatic choice.
-int g_gemm_f64_cfg = 0;
-int g_gemm_c128_cfg = 0;
 
 static bool fill_args(GemmArgs& g, const double* A, const double* B, double* C, int64_t m,
                       int64_t n, int64_t k, int64_t lda, int64_t ldb, int64_t ldc, int64_t batch,
@@ -285,6 +373,7 @@ static bool fill_args(GemmArgs& g, const double* A, const double* B, double* C, 
     g.m = (int)m; g.n = (int)n; g.k = (int)k;
     g.tiles_m = g.tiles_n = 0;
     g.accumulate = accumulate ? 1 : 0;
+    g.debug = g_gemm_debug;
     // Which operand is the stream that neighbouring tiles should share in L2:
     // a shared (stride-0) A, or a short-and-wide product, streams B.
     g.group_along_m = ((sa == 0 && batch > 1) || m < n) ? 1 : 0;
@@ -343,9 +432,12 @@ int gemm_f64(const double* A, const double* B, double* C, int64_t m, int64_t n, 
                      !(n & 1) && !(sa & 1) && !(sb & 1);
     int cfg = g_gemm_f64_cfg;
     if (cfg == 0) {
+        const int rc = gemm_fast_try(QS_F64, A, B, C, m, n, k, lda, ldb, ldc, batch, sa, sb, sc,
+                                     accumulate, g.group_along_m, stream);
+        if (rc != 1) return rc;
         static const TileShape cand[] = {
-            {1, 128, 128, 1.00}, {12, 96, 128, 0.97}, {13, 128, 96, 0.97}, {8, 96, 96, 0.96},
-            {9, 128, 64, 0.95},  {10, 64, 128, 0.95}, {5, 64, 64, 0.93},   {11, 32, 32, 0.60},
+            {1, 128, 128, 1.00}, {12, 96, 128, 0.98}, {13, 128, 96, 0.98}, {8, 96, 96, 0.96},
+            {5, 64, 64, 0.95},   {9, 128, 64, 0.90},  {10, 64, 128, 0.90}, {11, 32, 32, 0.73},
         };
         cfg = pick_shape(cand, sizeof(cand) / sizeof(cand[0]), m, n);
     }
@@ -361,9 +453,12 @@ int gemm_c128(const double* A, const double* B, double* C, int64_t m, int64_t n,
         return QS_ERR_BAD_EXTENT;
     int cfg = g_gemm_c128_cfg;
     if (cfg == 0) {
+        const int rc = gemm_fast_try(QS_C128, A, B, C, m, n, k, lda, ldb, ldc, batch, sa, sb, sc,
+                                     accumulate, g.group_along_m, stream);
+        if (rc != 1) return rc;
         static const TileShape cand[] = {
-            {1, 64, 128, 1.00}, {2, 128, 64, 1.00}, {7, 96, 64, 0.97}, {8, 64, 96, 0.97},
-            {6, 64, 64, 0.95},  {4, 32, 32, 0.62},
+            {1, 64, 128, 1.00}, {2, 128, 64, 1.00}, {6, 64, 64, 1.00}, {9, 96, 96, 0.97},
+            {7, 96, 64, 0.95},  {8, 64, 96, 0.95},  {4, 32, 32, 0.94},
         };
         cfg = pick_shape(cand, sizeof(cand) / sizeof(cand[0]), m, n);
     }

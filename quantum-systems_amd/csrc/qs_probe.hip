@@ -47,6 +47,33 @@ __global__ __launch_bounds__(256) void mfma_f64_probe_kernel(double* sink, int i
     }
 }
 
+// Variant with the GEMM's register pattern: 4 A fragments x 4 B fragments -> 16
+// accumulators (128 VGPRs), MFMAs issued in the (i, j) order of the GEMM.
+__global__ __launch_bounds__(256, 2) void mfma_f64_probe16_kernel(double* sink, int iters, double seed) {
+    f64x4 c[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) c[i][j] = f64x4{0, 0, 0, 0};
+    double a[4], b[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { a[i] = seed + 1e-3 * (threadIdx.x + i); b[i] = 1.0 - 1e-3 * (threadIdx.x + 7 * i); }
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                asm volatile("v_mfma_f64_16x16x4_f64 %0, %1, %2, %0" : "+v"(c[i][j]) : "v"(a[i]), "v"(b[j]));
+    }
+    asm volatile("s_nop 15\n\ts_nop 15\n\ts_nop 15" ::: "memory");
+    double r = 0.0;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) r += c[i][j][0] + c[i][j][3];
+    if (r == 12345.6789) sink[0] = r;
+}
+
 __global__ __launch_bounds__(256) void stream_copy_kernel(const f64x2* __restrict__ src,
                                                           f64x2* __restrict__ dst, int64_t n) {
     for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n;
@@ -66,8 +93,12 @@ extern "C" {
 int qs_probe_mfma_f64(void* sink, int64_t blocks, int64_t iters, void* stream) {
     if (!sink) return QS_ERR_NULL_POINTER;
     if (blocks <= 0 || iters <= 0 || blocks > (1 << 20) || iters > (1 << 24)) return QS_ERR_BAD_EXTENT;
-    hipLaunchKernelGGL(mfma_f64_probe_kernel, dim3((unsigned)blocks), dim3(256), 0,
-                       (hipStream_t)stream, (double*)sink, (int)iters, 0.5);
+    if (iters & 1)   // odd iteration counts select the 16-accumulator variant (2x the MFMAs per iteration)
+        hipLaunchKernelGGL(mfma_f64_probe16_kernel, dim3((unsigned)blocks), dim3(256), 0,
+                           (hipStream_t)stream, (double*)sink, (int)iters, 0.5);
+    else
+        hipLaunchKernelGGL(mfma_f64_probe_kernel, dim3((unsigned)blocks), dim3(256), 0,
+                           (hipStream_t)stream, (double*)sink, (int)iters, 0.5);
     return launch_status("mfma probe launch");
 }
 

@@ -305,3 +305,52 @@ def test_bad_arguments_raise(K):
         K.transform_two_body(u.cpu(), torch.zeros(4, 4, dtype=torch.float64))
     with pytest.raises(TypeError):
         K.antisymmetrize(u.to(torch.float16))
+
+
+# ------------------------------------------- exact-tiling fast path (qs_gemm_fast.hip)
+
+
+@pytest.mark.parametrize("cplx", [False, True])
+@pytest.mark.parametrize("m,n,k,batch", [(128, 128, 16, 1), (256, 128, 48, 1), (128, 256, 64, 3),
+                                          (64, 128, 24, 2), (64, 64, 8, 5), (384, 128, 40, 1)])
+def test_fast_path_product_vs_oracle(K, m, n, k, batch, cplx):
+    # products whose extents are whole tiles take the scalar-addressed kernel;
+    # checked against NumPy's matmul (what np.tensordot lowers to)
+    rng = np.random.default_rng(m + n + k + batch + cplx)
+    A = rng.standard_normal((m, k))
+    B = rng.standard_normal((batch, k, n))
+    if cplx:
+        A = A + 1j * rng.standard_normal((m, k))
+        B = B + 1j * rng.standard_normal((batch, k, n))
+    ref = np.matmul(A, B)
+    for fast in (1, 0):
+        K.tuning_set("gemm_fast", fast)
+        got = host(K.matmul(dev(A), dev(B)))
+        assert relerr(got, ref) <= 1e-13, f"fast={fast}"
+        # accumulate form: out += A.B
+        out = dev(ref.copy())
+        K.matmul(dev(A), dev(B), out=out, accumulate=True)
+        assert relerr(host(out), 2 * ref) <= 1e-13, f"fast={fast} accumulate"
+    K.tuning_set("gemm_fast", 1)
+
+
+@pytest.mark.parametrize("dt", [torch.float64, torch.complex128])
+def test_fast_and_general_kernels_agree_l128(K, dt):
+    l = 128
+    g = torch.Generator(device="cuda:0").manual_seed(11)
+    u = torch.rand(l, l, l, l, dtype=torch.float64, device="cuda:0", generator=g).to(dt)
+    C = torch.randn(l, l, dtype=torch.float64, device="cuda:0", generator=g).to(dt) / l**0.5
+    if dt == torch.complex128:
+        C = C + 1j * torch.randn(l, l, dtype=torch.float64, device="cuda:0", generator=g) / l**0.5
+    Ct = C.conj().T.contiguous()
+    K.tuning_set("gemm_fast", 1)
+    fast = K.transform_two_body(u, C, Ct)
+    K.tuning_set("gemm_fast", 0)
+    gen = K.transform_two_body(u, C, Ct)
+    K.tuning_set("gemm_fast", 1)
+    scale = gen.abs().max().item()
+    assert (fast - gen).abs().max().item() <= 1e-12 * scale
+    x, y, z, w = (torch.randn(l, dtype=torch.float64, device="cuda:0", generator=g).to(dt) for _ in range(4))
+    lhs = torch.einsum("pqrs,p,q,r,s->", fast, x, y, z, w)
+    rhs = torch.einsum("abcd,a,b,c,d->", u, Ct.T @ x, Ct.T @ y, C @ z, C @ w)
+    assert abs(lhs - rhs).item() <= 1e-10 * abs(rhs).item()

@@ -43,6 +43,9 @@ def sweep(l, dt, cfgs, key):
 
 
 if __name__ == "__main__":
+    pipe = int(os.environ.get("QS_PIPE", "1"))
+    K.tuning_set("gemm_pipe", pipe)
+    print("gemm_pipe =", pipe)
     ls = [int(x) for x in sys.argv[1:]] or [256, 192, 128, 55]
     for l in ls:
         sweep(l, torch.float64, [0, 1, 5, 8, 9, 10, 11, 12, 13], "gemm_f64_cfg")
