@@ -57,7 +57,9 @@ void gemm_fast_kernel(const FastArgs g) {
     constexpr int KS = KT / 4;
     constexpr int NT = 256;
     constexpr int BM = 32 * TM, BN = 32 * TN;
-    constexpr int SA = KT + 2, SB = BN + 16;
+    // B rows: complex fragments are ds_read_b64 (row stride = 16 mod 32 doubles is conflict-free);
+    // fp64 fragments are ds_read_b128 column PAIRS (row stride = 0 mod 32 is conflict-free)
+    constexpr int SA = KT + 2, SB = CX ? BN + 16 : BN;
     constexpr int NA = BM * 8 / NT;                     // 16-byte items per thread, A stage (8 items per row)
     constexpr int IPR_B = CX ? BN : BN / 2;             // 16-byte items per B row
     static_assert(IPR_B % 64 == 0, "a wave must stay inside one B row");
@@ -110,7 +112,9 @@ void gemm_fast_kernel(const FastArgs g) {
     double* st_a = As + (tid >> 3) * SA + (tid & 7) * (CX ? 1 : 2);
     double* st_b = Bs + (wave / WPR) * SB + (tid % IPR_B) * (CX ? 1 : 2);
     const double* rd_a = As + (wm * 16 * TM + (lane & 15)) * SA + (lane >> 4);
-    const double* rd_b = Bs + (lane >> 4) * SB + wn * 16 * TN + (lane & 15);
+    // fp64: lane c of n-tile pair (2jp, 2jp+1) owns the ADJACENT columns 32jp + 2c, 32jp + 2c + 1,
+    // so one 16-byte LDS read feeds two MFMA tiles and the epilogue stores 16 bytes per lane
+    const double* rd_b = Bs + (lane >> 4) * SB + wn * 16 * TN + (CX ? 1 : 2) * (lane & 15);
 
     f64x2 ra[NA], rb[NB];
 
@@ -160,8 +164,17 @@ void gemm_fast_kernel(const FastArgs g) {
         for (int p = 0; p < NP; ++p) {
 #pragma unroll
             for (int i = 0; i < TM; ++i) af[p][i] = as[p * BM * SA + i * 16 * SA + kk * 4];
+            if constexpr (CX) {
 #pragma unroll
-            for (int j = 0; j < TN; ++j) bf[p][j] = bs[p * KT * SB + kk * 4 * SB + j * 16];
+                for (int j = 0; j < TN; ++j) bf[p][j] = bs[p * KT * SB + kk * 4 * SB + j * 16];
+            } else {
+#pragma unroll
+                for (int jp = 0; jp < TN / 2; ++jp) {
+                    const f64x2 v = *reinterpret_cast<const f64x2*>(bs + kk * 4 * SB + jp * 32);
+                    bf[p][2 * jp] = v[0];
+                    bf[p][2 * jp + 1] = v[1];
+                }
+            }
         }
     };
     auto mfma_step = [&](const double (&af)[NP][TM], const double (&bf)[NP][TN]) {
@@ -220,25 +233,29 @@ void gemm_fast_kernel(const FastArgs g) {
         if (t + 1 < nk) stage(B1{}, t + 1);
     }
 
-    // ---- epilogue: reg r of a lane -> row (lane>>4) + 4r, col lane&15 of each 16x16 block
+    // ---- epilogue: reg r of a lane -> row (lane>>4) + 4r of each 16-row block; 16 bytes per lane
     double* __restrict__ C = g.C + (b * g.sc + (int64_t)(m0 + wm * 16 * TM + (lane >> 4)) * g.ldc +
-                                    n0 + wn * 16 * TN + (lane & 15)) * ES;
+                                    n0 + wn * 16 * TN + (CX ? 1 : 2) * (lane & 15)) * ES;
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             double* crow = C + (int64_t)(i * 16 + 4 * r) * g.ldc * ES;
+            if constexpr (CX) {
 #pragma unroll
-            for (int j = 0; j < TN; ++j) {
-                if constexpr (CX) {
+                for (int j = 0; j < TN; ++j) {
                     f64x2* dst = reinterpret_cast<f64x2*>(crow + 2 * j * 16);
                     f64x2 v = f64x2{acc[0][i][j][r], acc[1][i][j][r]};
                     if (g.accumulate) v += *dst;
                     *dst = v;
-                } else {
-                    double v = acc[0][i][j][r];
-                    if (g.accumulate) v += crow[j * 16];
-                    crow[j * 16] = v;
+                }
+            } else {
+#pragma unroll
+                for (int jp = 0; jp < TN / 2; ++jp) {
+                    f64x2* dst = reinterpret_cast<f64x2*>(crow + jp * 32);
+                    f64x2 v = f64x2{acc[0][i][2 * jp][r], acc[0][i][2 * jp + 1][r]};
+                    if (g.accumulate) v += *dst;
+                    *dst = v;
                 }
             }
         }
@@ -263,7 +280,7 @@ static int launch_fast(const double* A, const double* B, double* C, int64_t m, i
     g.accumulate = accumulate ? 1 : 0;
     const int64_t nwg = (int64_t)g.tiles_m * g.tiles_n * batch;
     if (nwg <= 0 || nwg >= (int64_t(1) << 31)) return QS_ERR_BAD_EXTENT;
-    const size_t lds = sizeof(double) * 2 * NP * (BM * (KT + 2) + KT * (BN + 16));
+    const size_t lds = sizeof(double) * 2 * NP * (BM * (KT + 2) + KT * (CX ? BN + 16 : BN));
     auto kern = gemm_fast_kernel<CX, TM, TN>;
     static bool lds_opt_in = false;
     if (lds > 64 * 1024 && !lds_opt_in) {
@@ -287,6 +304,7 @@ int gemm_fast_try(int dtype, const double* A, const double* B, double* C, int64_
     const int64_t esz = cx ? 16 : 8;
     if (!aligned(A, 16) || !aligned(B, 16) || !aligned(C, cx ? 16 : 8)) return 1;
     if (!cx && ((lda & 1) || (ldb & 1) || (sa & 1) || (sb & 1))) return 1;   // 16-byte loads
+    if (!cx && (!aligned(C, 16) || (ldc & 1) || (sc & 1))) return 1;          // 16-byte stores
     // the lane offset of the A loads is 32-bit: 32 rows of lda elements must fit
     if (32 * lda * esz + 256 >= (int64_t(1) << 32)) return 1;
 #define QS_FAST(CXF, TMF, TNF)                                                                      \

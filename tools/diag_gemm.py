@@ -1,5 +1,5 @@
-"""Steady-state rate of the GEMM kernel: large-K products where prologue,
-epilogue and workgroup launch are negligible, vs the l=256-shaped products."""
+"""Steady-state rate of the GEMM kernels: large-K products where prologue,
+epilogue and workgroup launch are negligible, vs K=256 (the l=256 transform)."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -12,16 +12,14 @@ def t(fn, reps=3):
         e0.record(); fn(); e1.record(); torch.cuda.synchronize(); ts.append(e0.elapsed_time(e1))
     return min(ts)
 for dt in (torch.float64, torch.complex128):
-    for (m, n, k) in [(8192, 8192, 256), (8192, 8192, 8192)]:
+    for (m, n, k) in [(8192, 8192, 128), (8192, 8192, 256), (8192, 8192, 512), (8192, 8192, 2048), (8192, 8192, 8192)]:
         A = torch.rand(m, k, dtype=torch.float64, device=dev).to(dt)
         B = torch.rand(k, n, dtype=torch.float64, device=dev).to(dt)
         C = torch.empty(m, n, dtype=dt, device=dev)
         kf = 4 if dt.is_complex else 1
-        for pipe in (0, 1):
-            K.tuning_set("gemm_pipe", pipe)
-            for dbg in (0, 2, 4):
-                K.tuning_set("gemm_debug", dbg)
-                ms = t(lambda: K.matmul(A, B, out=C))
-                print(f"{str(dt)[6:]:10s} {m}x{n}x{k:5d} pipe={pipe} debug={dbg}: {ms:8.2f} ms {kf*2*m*n*k/ms/1e9:6.2f} TFLOP/s", flush=True)
+        for fast in (0, 1):
+            K.tuning_set("gemm_fast", fast)
+            ms = t(lambda: K.matmul(A, B, out=C))
+            print(f"{str(dt)[6:]:10s} {m}x{n}x{k:5d} fast={fast}: {ms:8.2f} ms {kf*2*m*n*k/ms/1e9:6.2f} TFLOP/s", flush=True)
         del A, B, C
-K.tuning_set("gemm_debug", 0); K.tuning_set("gemm_pipe", 1)
+K.tuning_set("gemm_fast", 1)
