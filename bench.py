@@ -120,10 +120,13 @@ def cpu_baseline(l_max, budget_s=15.0):
         return dt
 
     run(32)                                   # BLAS thread pool warm-up
-    pilot = run(48)
-    l = int(min(l_max, max(48, 48 * (budget_s / max(pilot, 1e-3)) ** 0.2)))
-    l -= l % 8
-    dt = run(l)
+    l, dt = 64, run(64)
+    while dt < budget_s / 3 and l < l_max:    # grow the sample until it is worth ~budget_s
+        nxt = int(min(l_max, max(l + 16, l * (budget_s / max(dt, 1e-3)) ** 0.2)))
+        nxt -= nxt % 8
+        if nxt <= l:
+            break
+        l, dt = nxt, run(nxt)
     flops = orc.transform_flops(l, l)
     return {
         "value": flops / dt / 1e12, "unit": "TFLOP/s", "cores": int(threads), "kind": "port",
@@ -246,7 +249,7 @@ def main():
     roofline = {
         "bound": "mfma", "achieved": achieved, "peak": MFMA_F64_PEAK_TFLOPS, "unit": "TFLOP/s",
         "frac": achieved / MFMA_F64_PEAK_TFLOPS, "traffic": None,
-        "kernel": "qs::gemm_kernel (v_mfma_f64_16x16x4_f64)",
+        "kernel": "qs::gemm_fast_kernel<false,4,4> (v_mfma_f64_16x16x4_f64; qs::gemm_kernel for non-tile-multiple l)",
         "flops_per_launch": flops / world / launches_per_step,
         "avg_launch_ms": per_launch_s * 1e3,
     }

@@ -67,5 +67,6 @@ extern int g_gemm_c128_cfg;
 extern int g_gemm_pipe;
 extern int g_gemm_debug;
 extern int g_gemm_fast;
+extern int g_gemm_fast_persist;
 
 }  // namespace qs

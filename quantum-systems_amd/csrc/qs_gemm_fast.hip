@@ -4,21 +4,30 @@
 // Why a second kernel: on gfx950 the fp64 MFMA shares the SIMD's vector issue
 // with ordinary VALU work -- every VALU instruction in the K loop takes its
 // issue cycles away from the matrix pipe (measured with tools/probe_mix.hip:
-// 32 integer adds per 16 MFMAs cost 12 % of the MFMA rate, two co-resident
+// 32 integer adds per 16 MFMAs cost 12 % of the MFMA rate, and two co-resident
 // waves do not hide it).  The general kernel spends ~130 VALU instructions per
 // K step on 64-bit address arithmetic and edge handling.  This kernel is for
 // products whose extents are whole multiples of the tile (l = 128, 256, 512,
-// ...): the K loop then contains no VALU work at all --
+// ...); its K loop contains no VALU work at all:
 //   * global loads use the scalar-base form (SGPR pointer + one loop-invariant
 //     32-bit lane offset); the per-row bases advance on the scalar ALU;
 //   * LDS addresses are one VGPR + immediates (the loop is unrolled by two so
 //     the stage buffer is a compile-time constant);
 //   * no bounds checks, no zero fill.
-// Schedule (same as the general kernel's rotated schedule): fragments are
-// double-buffered in registers, k-step kk+1 is read while kk multiplies, and
-// the last k-step of a stage runs after the stage barrier while the next
-// stage's first fragments and the global loads of the stage after are in
-// flight, so the MFMA stream does not stop at the barrier.
+//
+// Persistent workgroups: 2 per CU, each walks its share of the tile list
+// (virtual block ids bid, bid + P, bid + 2P, ... of the XCD-chunked order the
+// general kernel uses, so concurrently running workgroups still share operand
+// panels in their XCD's L2).  The global stage stream is flat across tiles:
+// the loads for the first stages of tile n+1 are issued during the last stages
+// of tile n and its first fragments are read before tile n's epilogue, so the
+// MFMA stream only pauses for the issue of the epilogue stores.  (With one
+// workgroup per tile the prologue + epilogue + launch gap cost 8 % at K = 256.)
+//
+// Schedule inside a stage (rotated): fragments are double-buffered in
+// registers, k-step kk+1 is read while kk multiplies; the last k-step of a
+// stage runs after the stage barrier while the next stage's first fragments and
+// the global loads of the stage after are in flight.
 
 #include <type_traits>
 
@@ -37,15 +46,34 @@ struct FastArgs {
     int64_t sa, sb, sc;      // elements
     int nk;                  // K / KT
     int tiles_m, tiles_n;
+    unsigned total;          // tiles_m * tiles_n * batch = size of the virtual grid
     int group_along_m;
     int accumulate;
 };
 
-__device__ __forceinline__ unsigned xcd_chunked_index_fast(unsigned bid, unsigned nwg) {
-    const unsigned xcd = bid & 7u, slot = bid >> 3;
-    const unsigned q = nwg >> 3, r = nwg & 7u;
+// Work item of virtual block `v` of a `total`-block grid: XCD x (= v % 8) owns
+// the x-th contiguous chunk of the work list; bijective for every `total`.
+__device__ __forceinline__ unsigned xcd_chunked_index_fast(unsigned v, unsigned total) {
+    const unsigned xcd = v & 7u, slot = v >> 3;
+    const unsigned q = total >> 3, r = total & 7u;
     const unsigned base = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
     return base + slot;
+}
+
+// value known to be wave-uniform -> scalar registers
+__device__ __forceinline__ uint64_t uniform64(uint64_t x) {
+    const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)x);
+    const uint32_t hi = __builtin_amdgcn_readfirstlane((uint32_t)(x >> 32));
+    return ((uint64_t)hi << 32) | lo;
+}
+
+// 16-byte load at scalar base + 32-bit lane offset (buffer form, no range limit in use)
+__device__ __forceinline__ f64x2 load16(uint64_t base, unsigned lane_off) {
+    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+    const auto rsrc = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void*>(base), (short)0,
+                                                        (int)0xFFFFFFFF, 0x00020000);
+    const u32x4 raw = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)lane_off, 0, 0);
+    return __builtin_bit_cast(f64x2, raw);
 }
 
 template <bool CX, int TM, int TN>
@@ -69,6 +97,7 @@ void gemm_fast_kernel(const FastArgs g) {
     constexpr int A_STAGE = NP * BM * SA, B_STAGE = NP * KT * SB;
     constexpr size_t ESZ = 8 * ES;
     static_assert(KS % 2 == 0, "fragment double buffering needs an even k-step count");
+    static_assert(CX || TN % 2 == 0, "fp64 n-tiles come in column pairs");
 
     extern __shared__ __attribute__((aligned(16))) double smem[];
     double* As = smem;
@@ -78,31 +107,48 @@ void gemm_fast_kernel(const FastArgs g) {
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave >> 1, wn = wave & 1;
+    const int nk = g.nk;
+    const unsigned P = gridDim.x;                       // persistent grid (multiple of 8 unless P == total)
 
-    unsigned w = xcd_chunked_index_fast(blockIdx.x, gridDim.x);
-    int mt, nt;
-    if (g.group_along_m) {
-        mt = w % g.tiles_m; w /= g.tiles_m;
-        nt = w % g.tiles_n; w /= g.tiles_n;
-    } else {
-        nt = w % g.tiles_n; w /= g.tiles_n;
-        mt = w % g.tiles_m; w /= g.tiles_m;
-    }
-    const int64_t b = w;
-    const int m0 = mt * BM, n0 = nt * BN;
+    // tile coordinates of virtual block v
+    auto decode = [&](unsigned v, int& m0, int& n0, int64_t& b) {
+        unsigned w = xcd_chunked_index_fast(v, g.total);
+        int mt, nt;
+        if (g.group_along_m) {
+            mt = w % g.tiles_m; w /= g.tiles_m;
+            nt = w % g.tiles_n; w /= g.tiles_n;
+        } else {
+            nt = w % g.tiles_n; w /= g.tiles_n;
+            mt = w % g.tiles_m; w /= g.tiles_m;
+        }
+        // integer division runs on the vector ALU; bring the (wave-uniform) results back to
+        // scalar registers so that every pointer derived from them stays an SGPR base
+        b = __builtin_amdgcn_readfirstlane((int)w);
+        m0 = __builtin_amdgcn_readfirstlane(mt) * BM;
+        n0 = __builtin_amdgcn_readfirstlane(nt) * BN;
+    };
 
-    // ---- global addressing: scalar row bases + loop-invariant lane offsets
-    const char* a_ptr[NA];
-    const char* b_ptr[NB];
-    {
+    // ---- fetch cursor: scalar row bases of the tile being loaded + loop-invariant lane offsets
+    // Row bases are kept as scalar 64-bit integers and the loads go through buffer
+    // descriptors built from them: a descriptor lives in SGPRs by construction, which pins
+    // the scalar-base addressing even though the bases are re-aimed at every tile change.
+    uint64_t a_ptr[NA];
+    uint64_t b_ptr[NB];
+    unsigned f_v = blockIdx.x;   // virtual block the cursor is in
+    int f_k = 0;                 // next k-stage to load in that tile
+    bool f_valid = true;
+    auto aim = [&](unsigned v) {
+        int m0, n0; int64_t b;
+        decode(v, m0, n0, b);
         const char* Ab = reinterpret_cast<const char*>(g.A + (b * g.sa + (int64_t)m0 * g.lda) * ES);
         const char* Bb = reinterpret_cast<const char*>(g.B + (b * g.sb + n0) * ES);
 #pragma unroll
-        for (int i = 0; i < NA; ++i) a_ptr[i] = Ab + (size_t)i * 32 * g.lda * ESZ;
+        for (int i = 0; i < NA; ++i) a_ptr[i] = uniform64(reinterpret_cast<uint64_t>(Ab + (size_t)i * 32 * g.lda * ESZ));
         const int brow0 = wave / WPR;
 #pragma unroll
-        for (int i = 0; i < NB; ++i) b_ptr[i] = Bb + (size_t)(brow0 + i * RPS) * g.ldb * ESZ;
-    }
+        for (int i = 0; i < NB; ++i) b_ptr[i] = uniform64(reinterpret_cast<uint64_t>(Bb + (size_t)(brow0 + i * RPS) * g.ldb * ESZ));
+    };
+    aim(f_v);
     const unsigned voff_a = ((unsigned)(tid >> 3) * (unsigned)g.lda + (unsigned)(tid & 7) * (CX ? 1 : 2)) * (unsigned)ESZ;
     const unsigned voff_b = (unsigned)(tid % IPR_B) * 16u;
     const size_t a_step = KT * ESZ;
@@ -118,16 +164,24 @@ void gemm_fast_kernel(const FastArgs g) {
 
     f64x2 ra[NA], rb[NB];
 
+    // load the cursor's stage into registers and advance the cursor (to the
+    // next tile of this workgroup after the last k-stage)
     auto fetch = [&]() {
 #pragma unroll
         for (int i = 0; i < NA; ++i) {
-            ra[i] = *reinterpret_cast<const f64x2*>(a_ptr[i] + voff_a);
+            ra[i] = load16(a_ptr[i], voff_a);
             a_ptr[i] += a_step;
         }
 #pragma unroll
         for (int i = 0; i < NB; ++i) {
-            rb[i] = *reinterpret_cast<const f64x2*>(b_ptr[i] + voff_b);
+            rb[i] = load16(b_ptr[i], voff_b);
             b_ptr[i] += b_step;
+        }
+        if (++f_k == nk) {
+            f_k = 0;
+            f_v += P;
+            f_valid = f_v < g.total;
+            if (f_valid) aim(f_v);
         }
     };
 
@@ -149,12 +203,6 @@ void gemm_fast_kernel(const FastArgs g) {
     };
 
     f64x4 acc[NP][TM][TN];
-#pragma unroll
-    for (int p = 0; p < NP; ++p)
-#pragma unroll
-        for (int i = 0; i < TM; ++i)
-#pragma unroll
-            for (int j = 0; j < TN; ++j) acc[p][i][j] = f64x4{0.0, 0.0, 0.0, 0.0};
 
     auto read_frags = [&](auto buf_c, int kk, double (&af)[NP][TM], double (&bf)[NP][TN]) {
         constexpr int buf = decltype(buf_c)::value;
@@ -177,16 +225,19 @@ void gemm_fast_kernel(const FastArgs g) {
             }
         }
     };
-    auto mfma_step = [&](const double (&af)[NP][TM], const double (&bf)[NP][TN]) {
+    // `fresh`: first k-step of a tile -- the accumulators start from C = 0
+    auto mfma_step = [&](const double (&af)[NP][TM], const double (&bf)[NP][TN], auto fresh_c) {
+        constexpr bool fresh = decltype(fresh_c)::value;
+        const f64x4 zero = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
 #pragma unroll
             for (int j = 0; j < TN; ++j) {
                 if constexpr (!CX) {
-                    acc[0][i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[0][i], bf[0][j], acc[0][i][j], 0, 0, 0);
+                    acc[0][i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[0][i], bf[0][j], fresh ? zero : acc[0][i][j], 0, 0, 0);
                 } else {
-                    acc[0][i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[0][i], bf[0][j], acc[0][i][j], 0, 0, 0);
-                    acc[1][i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[0][i], bf[1][j], acc[1][i][j], 0, 0, 0);
+                    acc[0][i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[0][i], bf[0][j], fresh ? zero : acc[0][i][j], 0, 0, 0);
+                    acc[1][i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[0][i], bf[1][j], fresh ? zero : acc[1][i][j], 0, 0, 0);
                     acc[0][i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(-af[1][i], bf[1][j], acc[0][i][j], 0, 0, 0);
                     acc[1][i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[1][i], bf[0][j], acc[1][i][j], 0, 0, 0);
                 }
@@ -194,73 +245,102 @@ void gemm_fast_kernel(const FastArgs g) {
         }
     };
 
+    // epilogue of the tile at virtual block v: reg r of a lane -> row (lane>>4) + 4r of
+    // each 16-row block; 16 bytes per lane
+    auto epilogue = [&](unsigned v) {
+        int m0, n0; int64_t b;
+        decode(v, m0, n0, b);
+        double* __restrict__ C = g.C + (b * g.sc + (int64_t)(m0 + wm * 16 * TM + (lane >> 4)) * g.ldc +
+                                        n0 + wn * 16 * TN + (CX ? 1 : 2) * (lane & 15)) * ES;
+        auto store_all = [&](auto add_c) {
+            constexpr bool add = decltype(add_c)::value;
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    double* crow = C + (int64_t)(i * 16 + 4 * r) * g.ldc * ES;
+                    if constexpr (CX) {
+#pragma unroll
+                        for (int j = 0; j < TN; ++j) {
+                            f64x2* dst = reinterpret_cast<f64x2*>(crow + 2 * j * 16);
+                            f64x2 v2 = f64x2{acc[0][i][j][r], acc[1][i][j][r]};
+                            if constexpr (add) v2 += *dst;
+                            *dst = v2;
+                        }
+                    } else {
+#pragma unroll
+                        for (int jp = 0; jp < TN / 2; ++jp) {
+                            f64x2* dst = reinterpret_cast<f64x2*>(crow + jp * 32);
+                            f64x2 v2 = f64x2{acc[0][i][2 * jp][r], acc[0][i][2 * jp + 1][r]};
+                            if constexpr (add) v2 += *dst;
+                            *dst = v2;
+                        }
+                    }
+                }
+            }
+        };
+        if (g.accumulate) store_all(std::true_type{}); else store_all(std::false_type{});
+    };
+
     using B0 = std::integral_constant<int, 0>;
     using B1 = std::integral_constant<int, 1>;
+    using T_ = std::true_type;
+    using F_ = std::false_type;
 
-    const int nk = g.nk;
+    // number of tiles of this workgroup and of global stages
+    const unsigned my_tiles = (g.total - blockIdx.x + P - 1) / P;
+    const int64_t stages = (int64_t)my_tiles * nk;
+
     fetch();
     stash(B0{});
     __syncthreads();
-
     double a0[NP][TM], b0[NP][TN], a1[NP][TM], b1[NP][TN];
-    if (nk > 1) fetch();
+    if (f_valid) fetch();
     read_frags(B0{}, 0, a0, b0);
 
-    // one stage: k-steps 0 .. KS-2, [stash next stage], barrier, [fetch the stage
-    // after next], [first fragments of the next stage], k-step KS-1.  The three
-    // optional parts hang on wave-uniform conditions (scalar branches).
-    auto stage = [&](auto cur_c, int t) {
+    unsigned c_v = blockIdx.x;   // virtual block being computed
+    int c_k = 0;                 // its current k-stage
+
+    // one global stage: k-steps 0 .. KS-2, [stash the next stage], barrier, [fetch the
+    // stage after next], [first fragments of the next stage], k-step KS-1, and at a tile's
+    // last k-stage its epilogue.  All conditions are wave-uniform (scalar branches).
+    auto stage = [&](auto cur_c, int64_t gs) {
         constexpr int cur = decltype(cur_c)::value;
         using NXT = std::integral_constant<int, cur ^ 1>;
-        const bool has_next = t + 1 < nk, has_next2 = t + 2 < nk;
+        const bool has_next = gs + 1 < stages;
+        // k-step 0 (fresh accumulators at the start of a tile)
+        read_frags(cur_c, 1, a1, b1);
+        __builtin_amdgcn_sched_barrier(0);
+        if (c_k == 0) mfma_step(a0, b0, T_{}); else mfma_step(a0, b0, F_{});
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int kk = 0; kk + 1 < KS; ++kk) {
-            if ((kk & 1) == 0) { read_frags(cur_c, kk + 1, a1, b1); __builtin_amdgcn_sched_barrier(0); mfma_step(a0, b0); }
-            else               { read_frags(cur_c, kk + 1, a0, b0); __builtin_amdgcn_sched_barrier(0); mfma_step(a1, b1); }
+        for (int kk = 1; kk + 1 < KS; ++kk) {
+            if ((kk & 1) == 0) { read_frags(cur_c, kk + 1, a1, b1); __builtin_amdgcn_sched_barrier(0); mfma_step(a0, b0, F_{}); }
+            else               { read_frags(cur_c, kk + 1, a0, b0); __builtin_amdgcn_sched_barrier(0); mfma_step(a1, b1, F_{}); }
             __builtin_amdgcn_sched_barrier(0);
         }
         if (has_next) stash(NXT{});
         __syncthreads();
-        if (has_next2) fetch();
+        if (f_valid) fetch();
         if (has_next) read_frags(NXT{}, 0, a0, b0);
         __builtin_amdgcn_sched_barrier(0);
-        mfma_step(a1, b1);
+        mfma_step(a1, b1, F_{});
         __builtin_amdgcn_sched_barrier(0);
+        if (++c_k == nk) {
+            epilogue(c_v);
+            c_k = 0;
+            c_v += P;
+        }
     };
 
-    for (int t = 0; t < nk; t += 2) {
-        stage(B0{}, t);
-        if (t + 1 < nk) stage(B1{}, t + 1);
-    }
-
-    // ---- epilogue: reg r of a lane -> row (lane>>4) + 4r of each 16-row block; 16 bytes per lane
-    double* __restrict__ C = g.C + (b * g.sc + (int64_t)(m0 + wm * 16 * TM + (lane >> 4)) * g.ldc +
-                                    n0 + wn * 16 * TN + (CX ? 1 : 2) * (lane & 15)) * ES;
-#pragma unroll
-    for (int i = 0; i < TM; ++i) {
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            double* crow = C + (int64_t)(i * 16 + 4 * r) * g.ldc * ES;
-            if constexpr (CX) {
-#pragma unroll
-                for (int j = 0; j < TN; ++j) {
-                    f64x2* dst = reinterpret_cast<f64x2*>(crow + 2 * j * 16);
-                    f64x2 v = f64x2{acc[0][i][j][r], acc[1][i][j][r]};
-                    if (g.accumulate) v += *dst;
-                    *dst = v;
-                }
-            } else {
-#pragma unroll
-                for (int jp = 0; jp < TN / 2; ++jp) {
-                    f64x2* dst = reinterpret_cast<f64x2*>(crow + jp * 32);
-                    f64x2 v = f64x2{acc[0][i][2 * jp][r], acc[0][i][2 * jp + 1][r]};
-                    if (g.accumulate) v += *dst;
-                    *dst = v;
-                }
-            }
-        }
+    for (int64_t gs = 0; gs < stages; gs += 2) {
+        stage(B0{}, gs);
+        if (gs + 1 < stages) stage(B1{}, gs + 1);
     }
 }
+
+int g_gemm_fast = 1;           // tuning knob: 0 routes everything through the general kernel
+int g_gemm_fast_persist = 1;   // tuning knob: 0 one workgroup per tile, 1 automatic, 2 always persistent
 
 template <bool CX, int TM, int TN>
 static int launch_fast(const double* A, const double* B, double* C, int64_t m, int64_t n, int64_t k,
@@ -278,8 +358,30 @@ static int launch_fast(const double* A, const double* B, double* C, int64_t m, i
     g.tiles_n = (int)(n / BN);
     g.group_along_m = group_along_m;
     g.accumulate = accumulate ? 1 : 0;
-    const int64_t nwg = (int64_t)g.tiles_m * g.tiles_n * batch;
-    if (nwg <= 0 || nwg >= (int64_t(1) << 31)) return QS_ERR_BAD_EXTENT;
+    const int64_t total = (int64_t)g.tiles_m * g.tiles_n * batch;
+    if (total <= 0 || total >= (int64_t(1) << 31)) return QS_ERR_BAD_EXTENT;
+    g.total = (unsigned)total;
+    // two persistent workgroups per CU (the LDS and register budget admits exactly two)
+    static int n_cu = 0;
+    if (n_cu == 0) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) {
+            (void)hipGetLastError();
+            n_cu = 256;
+        } else {
+            n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+        }
+    }
+    int64_t P = 2 * (int64_t)n_cu;
+    P -= P % 8;
+    // Persistent walking pays on short tile lists (fewer launch gaps, cross-tile prefetch:
+    // +7 % at l = 64); on long lists the static split loses more to uneven CU progress than
+    // the prefetch wins (-4 % at l = 256, profiles/r01_gemm_notes.txt), so those keep one
+    // workgroup per tile and let the dispatcher balance.  g_gemm_fast_persist: 0 never,
+    // 1 automatic, 2 always.
+    const bool persist = g_gemm_fast_persist == 2 || (g_gemm_fast_persist == 1 && total <= 8 * P);
+    if (!persist || total <= P) P = total;
     const size_t lds = sizeof(double) * 2 * NP * (BM * (KT + 2) + KT * (CX ? BN + 16 : BN));
     auto kern = gemm_fast_kernel<CX, TM, TN>;
     static bool lds_opt_in = false;
@@ -288,11 +390,9 @@ static int launch_fast(const double* A, const double* B, double* C, int64_t m, i
         if (e != hipSuccess) return hip_status(e, "hipFuncSetAttribute(gemm_fast)");
         lds_opt_in = true;
     }
-    hipLaunchKernelGGL(kern, dim3((unsigned)nwg), dim3(256), lds, stream, g);
+    hipLaunchKernelGGL(kern, dim3((unsigned)P), dim3(256), lds, stream, g);
     return launch_status("gemm_fast launch");
 }
-
-int g_gemm_fast = 1;   // tuning knob: 0 routes everything through the general kernel
 
 // Returns QS_OK after launching, or 1 when the product does not qualify for a
 // fast shape (caller falls back to the general kernel).
