@@ -74,11 +74,21 @@ __global__ __launch_bounds__(256, 2) void mfma_f64_probe16_kernel(double* sink, 
     if (r == 12345.6789) sink[0] = r;
 }
 
+// 4 x 16 bytes per thread, all loads issued before the stores, one block per 16 KiB
 __global__ __launch_bounds__(256) void stream_copy_kernel(const f64x2* __restrict__ src,
                                                           f64x2* __restrict__ dst, int64_t n) {
-    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n;
-         i += (int64_t)gridDim.x * blockDim.x)
-        dst[i] = src[i];
+    const int64_t base = (int64_t)blockIdx.x * 1024 + threadIdx.x;
+    f64x2 v[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int64_t k = base + i * 256;
+        if (k < n) v[i] = src[k];
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int64_t k = base + i * 256;
+        if (k < n) dst[k] = v[i];
+    }
 }
 
 }  // namespace qs
@@ -107,8 +117,11 @@ int qs_probe_stream_copy(const void* src, void* dst, int64_t bytes, void* stream
     if (!src || !dst) return QS_ERR_NULL_POINTER;
     if (bytes <= 0 || (bytes & 15)) return QS_ERR_BAD_EXTENT;
     if (!aligned(src, 16) || !aligned(dst, 16)) return QS_ERR_MISALIGNED;
-    hipLaunchKernelGGL(stream_copy_kernel, dim3(256 * 8), dim3(256), 0, (hipStream_t)stream,
-                       (const f64x2*)src, (f64x2*)dst, bytes / 16);
+    const int64_t n = bytes / 16;
+    const int64_t blocks = (n + 1023) / 1024;
+    if (blocks >= (int64_t(1) << 31)) return QS_ERR_BAD_EXTENT;
+    hipLaunchKernelGGL(stream_copy_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream,
+                       (const f64x2*)src, (f64x2*)dst, n);
     return launch_status("stream copy launch");
 }
 
