@@ -1,6 +1,6 @@
 """Headline benchmark: four-index transform of the two-body integrals.
 
-    python bench.py [--gpus N --steps K --warmup W] [--l 256] [--dtype f64|c128]
+    python bench.py [--gpus N --steps K --warmup W] [--orbitals 256] [--dtype f64|c128]
                     [--layout replicated|sharded] [--gather] [--no-cpu-baseline]
 
 Metric (BASELINE.json): "4-index u transform TFLOP/s (fp64) at L orbitals".
@@ -35,7 +35,8 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--l", type=int, default=256)
+    ap.add_argument("--orbitals", "-l", dest="l", type=int, default=256,
+                    help="number of orbitals l (named so that torch.distributed.run does not read it as --l*)")
     ap.add_argument("--dtype", choices=["f64", "c128"], default="f64")
     ap.add_argument("--layout", choices=["replicated", "sharded"], default="replicated")
     ap.add_argument("--gather", action="store_true", help="include the all-gather of the result")
@@ -136,6 +137,21 @@ def cpu_baseline(l_max, budget_s=15.0):
     }
 
 
+class _StdoutToStderr:
+    """RCCL prints a version banner on STDOUT when the communicator is created; the
+    bench contract is one JSON line on stdout, so fd 1 points at stderr meanwhile."""
+
+    def __enter__(self):
+        sys.stdout.flush()
+        self._saved = os.dup(1)
+        os.dup2(2, 1)
+
+    def __exit__(self, *exc):
+        sys.stdout.flush()
+        os.dup2(self._saved, 1)
+        os.close(self._saved)
+
+
 def main():
     args = parse()
     import torch
@@ -149,11 +165,26 @@ def main():
             raise SystemExit("launch N>1 with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N")
         args.gpus = world
     assert torch.cuda.is_available(), "bench.py needs a GPU (no CPU path)"
-    torch.cuda.set_device(local_rank)
-    device = torch.device("cuda", local_rank)
-    if world > 1:
+    # rehearsal hooks for a one-GPU box (never set by the driver): all ranks on cuda:0 over
+    # gloo, or a one-rank RCCL group, to walk the multi-rank code paths without 8 GPUs
+    single_dev = os.environ.get("QS_BENCH_SINGLE_DEVICE") == "1"
+    backend = os.environ.get("QS_BENCH_BACKEND", "nccl")
+    dev_index = 0 if single_dev else local_rank
+    torch.cuda.set_device(dev_index)
+    device = torch.device("cuda", dev_index)
+    use_dist = world > 1 or os.environ.get("QS_BENCH_FORCE_DIST") == "1"
+    if use_dist:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", device_id=device)
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29611")
+        with _StdoutToStderr():
+            if backend == "nccl":
+                dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+            else:
+                dist.init_process_group(backend, rank=rank, world_size=world)
+            warm = torch.ones(1, dtype=torch.float64, device=device)
+            dist.all_reduce(warm)          # creates the communicator (and its banner) now
+            torch.cuda.synchronize()
 
     from quantum_systems_amd import _lib, kernels, sharded
 
@@ -167,7 +198,7 @@ def main():
     part = sharded.SlabPartition(l, world)
     p_lo, p_hi = part.bounds(rank)
 
-    if world == 1:
+    if world == 1 and not use_dist:
         out = torch.empty_like(u)
 
         def step():
@@ -198,7 +229,7 @@ def main():
         layout = "u b-sharded, one all-to-all, out p-sharded" + (", +all-gather" if args.gather else "")
 
     def barrier():
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -216,17 +247,17 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     dev_elapsed = ev0.elapsed_time(ev1) * 1e-3       # same stream as the kernels
-    if world > 1:
+    if use_dist:
         t = torch.tensor([elapsed, dev_elapsed], dtype=torch.float64, device=device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed, dev_elapsed = t[0].item(), t[1].item()
 
     # parity property at full size on this rank's rows
     if u is not None:
-        rows = res[p_lo:p_hi] if (world == 1 or args.gather) else res
+        rows = res[p_lo:p_hi] if ((world == 1 and not use_dist) or args.gather) else res
         lhs, rhs = identity_check(torch, u, rows, C, Ct, p_lo)
         pair = torch.stack([lhs, rhs]).to(torch.complex128)
-        if world > 1:
+        if use_dist:
             pr = torch.view_as_real(pair).contiguous()
             dist.all_reduce(pr)
             pair = torch.view_as_complex(pr)
@@ -235,7 +266,7 @@ def main():
         rel = None
 
     if rank != 0:
-        if world > 1:
+        if use_dist:
             dist.barrier()
             dist.destroy_process_group()
         return
@@ -309,7 +340,7 @@ def main():
         del res
         line["cpu_baseline"] = cpu_baseline(args.cpu_l)
     print(json.dumps(line), flush=True)
-    if world > 1:
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
 

@@ -47,6 +47,11 @@ int gemm_fast_try(int dtype, const double* A, const double* B, double* C, int64_
                   int64_t k, int64_t lda, int64_t ldb, int64_t ldc, int64_t batch, int64_t sa,
                   int64_t sb, int64_t sc, int accumulate, int group_along_m, hipStream_t stream);
 
+// Short-and-wide streaming product (qs_gemm_skinny.hip): same return convention.
+int gemm_skinny_try(int dtype, const double* A, const double* B, double* C, int64_t m, int64_t n,
+                    int64_t k, int64_t lda, int64_t ldb, int64_t ldc, int64_t batch, int accumulate,
+                    hipStream_t stream);
+
 // out (cols, rows) = in (rows, cols)^T, element = 8 or 16 bytes (tiny helper
 // for the coefficient matrices).
 int transpose_small(int dtype, const void* in, void* out, int64_t rows,
@@ -68,5 +73,6 @@ extern int g_gemm_pipe;
 extern int g_gemm_debug;
 extern int g_gemm_fast;
 extern int g_gemm_fast_persist;
+extern int g_gemm_skinny;
 
 }  // namespace qs

@@ -432,8 +432,10 @@ int gemm_f64(const double* A, const double* B, double* C, int64_t m, int64_t n, 
                      !(n & 1) && !(sa & 1) && !(sb & 1);
     int cfg = g_gemm_f64_cfg;
     if (cfg == 0) {
-        const int rc = gemm_fast_try(QS_F64, A, B, C, m, n, k, lda, ldb, ldc, batch, sa, sb, sc,
-                                     accumulate, g.group_along_m, stream);
+        int rc = gemm_skinny_try(QS_F64, A, B, C, m, n, k, lda, ldb, ldc, batch, accumulate, stream);
+        if (rc != 1) return rc;
+        rc = gemm_fast_try(QS_F64, A, B, C, m, n, k, lda, ldb, ldc, batch, sa, sb, sc,
+                           accumulate, g.group_along_m, stream);
         if (rc != 1) return rc;
         static const TileShape cand[] = {
             {1, 128, 128, 1.00}, {12, 96, 128, 0.98}, {13, 128, 96, 0.98}, {8, 96, 96, 0.96},
@@ -453,8 +455,10 @@ int gemm_c128(const double* A, const double* B, double* C, int64_t m, int64_t n,
         return QS_ERR_BAD_EXTENT;
     int cfg = g_gemm_c128_cfg;
     if (cfg == 0) {
-        const int rc = gemm_fast_try(QS_C128, A, B, C, m, n, k, lda, ldb, ldc, batch, sa, sb, sc,
-                                     accumulate, g.group_along_m, stream);
+        int rc = gemm_skinny_try(QS_C128, A, B, C, m, n, k, lda, ldb, ldc, batch, accumulate, stream);
+        if (rc != 1) return rc;
+        rc = gemm_fast_try(QS_C128, A, B, C, m, n, k, lda, ldb, ldc, batch, sa, sb, sc,
+                           accumulate, g.group_along_m, stream);
         if (rc != 1) return rc;
         static const TileShape cand[] = {
             {1, 64, 128, 1.00}, {2, 128, 64, 1.00}, {6, 64, 64, 1.00}, {9, 96, 96, 0.97},

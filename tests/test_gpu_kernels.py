@@ -354,3 +354,42 @@ def test_fast_and_general_kernels_agree_l128(K, dt):
     lhs = torch.einsum("pqrs,p,q,r,s->", fast, x, y, z, w)
     rhs = torch.einsum("abcd,a,b,c,d->", u, Ct.T @ x, Ct.T @ y, C @ z, C @ w)
     assert abs(lhs - rhs).item() <= 1e-10 * abs(rhs).item()
+
+
+# ------------------------------------------- short-and-wide streaming product (qs_gemm_skinny.hip)
+
+
+@pytest.mark.parametrize("cplx", [False, True])
+@pytest.mark.parametrize("m,k", [(16, 8), (32, 64), (48, 20), (64, 36)])
+def test_skinny_product_vs_oracle(K, m, k, cplx):
+    # the leading-index contraction of the sharded layout: few rows of Ct times the whole tensor
+    rng = np.random.default_rng(m * 100 + k + cplx)
+    n = 1 << 16
+    A = rng.standard_normal((m, k))
+    B = rng.standard_normal((k, n))
+    if cplx:
+        A = A + 1j * rng.standard_normal((m, k))
+        B = B + 1j * rng.standard_normal((k, n))
+    ref = A @ B
+    for skinny in (1, 0):
+        K.tuning_set("gemm_skinny", skinny)
+        got = host(K.matmul(dev(A), dev(B)))
+        assert relerr(got, ref) <= 1e-13, f"skinny={skinny}"
+    K.tuning_set("gemm_skinny", 1)
+
+
+def test_replicated_layout_matches_full_transform(K):
+    # sharded.transform_two_body_replicated on one GPU, every rank's slab (uses the skinny product)
+    from quantum_systems_amd import sharded
+
+    l = 64
+    g = torch.Generator(device="cuda:0").manual_seed(21)
+    u = torch.rand(l, l, l, l, dtype=torch.float64, device="cuda:0", generator=g)
+    C = torch.randn(l, l, dtype=torch.float64, device="cuda:0", generator=g) / 8
+    Ct = torch.randn(l, l, dtype=torch.float64, device="cuda:0", generator=g) / 8
+    full = K.transform_two_body(u, C, Ct)
+    for world in (2, 4):
+        for rank in range(world):
+            lo, hi = sharded.SlabPartition(l, world).bounds(rank)
+            slab = sharded.transform_two_body_replicated(u, C, Ct, rank, world)
+            assert (slab - full[lo:hi]).abs().max().item() <= 1e-12 * full.abs().max().item()
