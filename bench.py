@@ -43,6 +43,9 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-l", type=int, default=176, help="largest size of the CPU-baseline sample")
     ap.add_argument("--no-probes", action="store_true")
+    ap.add_argument("--workload", choices=["transform", "spin_expand", "antisymmetrize"], default="transform",
+                    help="transform = the headline metric; the other two are the HBM-bound kernels of "
+                         "BASELINE.json configs[3] (own metric names, same JSON shape)")
     return ap.parse_args()
 
 
@@ -137,6 +140,102 @@ def cpu_baseline(l_max, budget_s=15.0):
     }
 
 
+HBM_PEAK_GBPS = 8000.0   # MI355X_MICROARCH.md: 8 TB/s spec (6.3 TB/s measured achievable)
+
+
+def bandwidth_workload(args, torch, dist, kernels, sharded, device, rank, world, use_dist):
+    """BASELINE.json configs[3]: spatial real fp64 u at l (default 256), p-slab per rank,
+    fused spin expansion + anti-symmetrisation + complex cast to 2l spin orbitals
+    (264*l^4 algorithmic bytes), or the stand-alone anti-symmetrisation (16*l^4).  The spin
+    tensor (1.1 TB at l=256) is streamed slab by slab through one reused output buffer."""
+    l = args.l
+    part = sharded.SlabPartition(l, world)
+    p_lo, p_hi = part.bounds(rank)
+    g = torch.Generator(device=device).manual_seed(4321)
+    u = torch.empty((l, l, l, l), dtype=torch.float64, device=device)
+    for lo in range(0, l, 8):
+        u[lo:lo + 8] = torch.rand((min(8, l - lo), l, l, l), dtype=torch.float64, device=device, generator=g) - 0.5
+    if args.workload == "spin_expand":
+        rows = max(1, min(p_hi - p_lo, int(40e9 // (2 * (2 * l) ** 3 * 16))))
+        buf = torch.empty((2 * rows, 2 * l, 2 * l, 2 * l), dtype=torch.complex128, device=device)
+
+        def step():
+            for p0 in range(p_lo, p_hi, rows):
+                p1 = min(p_hi, p0 + rows)
+                kernels.spin_expand_two_body(u, antisymmetrize=True, out_dtype=torch.complex128,
+                                             p_lo=p0, p_hi=p1, out=buf[: 2 * (p1 - p0)])
+        step_bytes = (8 * l**3 + 16 * 2 * (2 * l) ** 3) * l
+        launches = -(-(p_hi - p_lo) // rows)
+        name = "fused spin-expand + antisymmetrise + complex cast"
+        kernel = "qs::spin_expand_kernel<double, f64x2>"
+    else:
+        src = u[p_lo:p_hi]
+        out = torch.empty_like(src)
+
+        def step():
+            kernels.antisymmetrize(src, out=out)
+        step_bytes = 16 * l**4
+        launches = 1
+        name = "anti-symmetrise u"
+        kernel = "qs::antisym_kernel<double>"
+
+    def barrier():
+        if use_dist:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t0 = time.perf_counter()
+    e0.record()
+    for _ in range(args.steps):
+        step()
+    e1.record()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    dev_elapsed = e0.elapsed_time(e1) * 1e-3
+    if use_dist:
+        t = torch.tensor([elapsed, dev_elapsed], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed, dev_elapsed = t[0].item(), t[1].item()
+    # parity (value-exact): the first local p row against the definition written with torch ops
+    row = u[p_lo:p_lo + 1]
+    if args.workload == "spin_expand":
+        got = kernels.spin_expand_two_body(u, antisymmetrize=True, out_dtype=torch.complex128, p_lo=p_lo, p_hi=p_lo + 1)
+        eye = torch.eye(2, dtype=torch.float64, device=device)
+        ref = torch.einsum("pqrs,ac,bd->paqbrcsd", row, eye, eye).reshape(2, 2 * l, 2 * l, 2 * l)
+        ref = (ref - ref.transpose(2, 3)).to(torch.complex128)
+    else:
+        got = kernels.antisymmetrize(row)
+        ref = row - row.transpose(2, 3)
+    exact = bool(torch.equal(got, ref))
+    if rank == 0:
+        gbps = step_bytes * args.steps / elapsed / 1e9
+        per_launch = dev_elapsed / (args.steps * launches)
+        achieved = step_bytes / world / launches / per_launch / 1e9
+        line = {
+            "metric": f"{name} GB/s (algorithmic bytes) at l={l} spatial orbitals",
+            "value": gbps, "unit": "GB/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "strong",
+            "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": f"BASELINE.json configs[3]: spatial real fp64 u l={l} -> "
+                                   f"{2*l} spin orbitals complex128, p-slab per GPU, output streamed "
+                                   f"through a reused slab buffer" if args.workload == "spin_expand"
+                                   else f"anti-symmetrisation of real fp64 u l={l}, p-slab per GPU",
+                       "l": l, "bytes_per_step": step_bytes},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBPS, "traffic": None, "kernel": kernel,
+                         "bytes_per_launch": step_bytes / world / launches, "avg_launch_ms": per_launch * 1e3},
+            "parity": {"value_exact_vs_definition": exact},
+        }
+        print(json.dumps(line), flush=True)
+    if use_dist:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
 class _StdoutToStderr:
     """RCCL prints a version banner on STDOUT when the communicator is created; the
     bench contract is one JSON line on stdout, so fd 1 points at stderr meanwhile."""
@@ -189,6 +288,8 @@ def main():
     from quantum_systems_amd import _lib, kernels, sharded
 
     lib = _lib.load()
+    if args.workload != "transform":
+        return bandwidth_workload(args, torch, dist, kernels, sharded, device, rank, world, use_dist)
     l = args.l
     dtype = torch.float64 if args.dtype == "f64" else torch.complex128
     kf = 1 if args.dtype == "f64" else 4

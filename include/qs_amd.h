@@ -167,8 +167,11 @@ int qs_spin_squared_two_body(const void* S, void* out, int64_t n, int64_t p_lo,
 /*
  * Auxiliary entry points (no reference counterpart).
  *   qs_tuning_set: override a kernel choice for tuning runs; keys
- *     "gemm_f64_cfg", "gemm_c128_cfg" (tile shape, 0 = automatic) and
- *     "gemm_pipe" (1 = rotated K-loop schedule, 0 = plain schedule).
+ *     "gemm_f64_cfg", "gemm_c128_cfg" (tile shape of the general
+ *     kernel, 0 = automatic), "gemm_pipe" (1 = rotated K-loop schedule, 0 = plain),
+ *     "gemm_fast" (0 = never use the exact-tiling kernel), "gemm_fast_persist"
+ *     (0 one workgroup per tile, 1 automatic, 2 always persistent),
+ *     "gemm_skinny" (0 = never use the streaming short-and-wide kernel).
  *   qs_probe_mfma_f64: register-resident fp64 MFMA loop, `blocks` workgroups
  *     of 4 waves, each wave issuing iters*8 v_mfma_f64_16x16x4_f64
  *     (flops = blocks*4*iters*8*2048); `sink` is a device scratch of

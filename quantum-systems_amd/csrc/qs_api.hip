@@ -83,7 +83,6 @@ int qs_tuning_set(const char* key, int64_t value) {
     if (!strcmp(key, "gemm_f64_cfg")) { g_gemm_f64_cfg = (int)value; return QS_OK; }
     if (!strcmp(key, "gemm_c128_cfg")) { g_gemm_c128_cfg = (int)value; return QS_OK; }
     if (!strcmp(key, "gemm_pipe")) { g_gemm_pipe = (int)value; return QS_OK; }
-    if (!strcmp(key, "gemm_debug")) { g_gemm_debug = (int)value; return QS_OK; }
     if (!strcmp(key, "gemm_fast")) { g_gemm_fast = (int)value; return QS_OK; }
     if (!strcmp(key, "gemm_skinny")) { g_gemm_skinny = (int)value; return QS_OK; }
     if (!strcmp(key, "gemm_fast_persist")) { g_gemm_fast_persist = (int)value; return QS_OK; }

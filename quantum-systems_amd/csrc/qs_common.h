@@ -70,7 +70,6 @@ int spin2_two_body(const void* S, void* out, int64_t n, int64_t p_lo, int64_t p_
 extern int g_gemm_f64_cfg;
 extern int g_gemm_c128_cfg;
 extern int g_gemm_pipe;
-extern int g_gemm_debug;
 extern int g_gemm_fast;
 extern int g_gemm_fast_persist;
 extern int g_gemm_skinny;

@@ -54,7 +54,6 @@ struct GemmArgs {
     int tiles_m, tiles_n;
     int group_along_m;   // 1: tiles that share a B panel (same n-tile) are adjacent
     int accumulate;      // 1: C += A.B (C is read in the epilogue), 0: C = A.B
-    int debug;           // DIAGNOSTIC ONLY (qs_tuning_set "gemm_debug"): bit0 skip epilogue stores
 };
 
 // Work index of a workgroup: XCD x gets the x-th contiguous chunk of the work
@@ -223,12 +222,6 @@ void gemm_kernel(const GemmArgs g) {
         }
     };
 
-    if (g.debug & 6) {   // DIAGNOSTIC: asymmetric wave priority between co-resident workgroups
-        unsigned hwid;
-        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
-        const unsigned sel = (g.debug & 2) ? (blockIdx.x & 1u) : ((hwid >> 0) & 1u);   // bit1: block parity, bit2: wave-slot parity
-        if (__builtin_amdgcn_readfirstlane(sel)) __builtin_amdgcn_s_setprio(2);
-    }
     fetch(0);
     stash(0, 0);
     __syncthreads();
@@ -285,17 +278,6 @@ void gemm_kernel(const GemmArgs g) {
         stage(t, F_{}, F_{}, F_{});
     }
 
-    if (g.debug & 1) {   // DIAGNOSTIC bit0: timing experiment: no stores (keeps the accumulators alive)
-        double keep = 0.0;
-#pragma unroll
-        for (int p = 0; p < NP; ++p)
-#pragma unroll
-            for (int i = 0; i < TM; ++i)
-#pragma unroll
-                for (int j = 0; j < TN; ++j) keep += acc[p][i][j][0] + acc[p][i][j][1] + acc[p][i][j][2] + acc[p][i][j][3];
-        if (keep == 1.2345e-300) C[0] = keep;
-        return;
-    }
     // epilogue: reg r of a lane -> row (lane>>4) + 4r, col lane&15 of each 16x16 block
     const int crow = m0 + wm * 16 * TM + (lane >> 4);
     const int ccol = n0 + wn * 16 * TN + (lane & 15);
@@ -330,7 +312,6 @@ void gemm_kernel(const GemmArgs g) {
 // Schedule / tile-shape overrides for tuning runs (qs_tuning_set); 0 = automatic.
 int g_gemm_f64_cfg = 0;
 int g_gemm_c128_cfg = 0;
-int g_gemm_debug = 0;    // diagnostic bits, see GemmArgs::debug
 int g_gemm_pipe = 1;     // 1: rotated K-loop schedule, 0: plain schedule (A/B reference)
 
 template <int WM, int WN, int TM, int TN, int KT, int MODE>
@@ -373,7 +354,6 @@ static bool fill_args(GemmArgs& g, const double* A, const double* B, double* C, 
     g.m = (int)m; g.n = (int)n; g.k = (int)k;
     g.tiles_m = g.tiles_n = 0;
     g.accumulate = accumulate ? 1 : 0;
-    g.debug = g_gemm_debug;
     // Which operand is the stream that neighbouring tiles should share in L2:
     // a shared (stride-0) A, or a short-and-wide product, streams B.
     g.group_along_m = ((sa == 0 && batch > 1) || m < n) ? 1 : 0;

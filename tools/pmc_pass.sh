@@ -23,3 +23,5 @@ run lds SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_LDS SQ_WAIT_INST_LDS SQ_
 cd $ROOTDIR
 python3 tools/pmc_summarise.py $OUT > $OUT/summary.txt 2>&1
 cat $OUT/summary.txt
+# the raw rocprofv3 directories are large; only the summary travels back
+for d in fetch write clk lds; do rm -rf $OUT/$d; done
