@@ -162,19 +162,22 @@ void gemm_fast_kernel(const FastArgs g) {
     // so one 16-byte LDS read feeds two MFMA tiles and the epilogue stores 16 bytes per lane
     const double* rd_b = Bs + (lane >> 4) * SB + wn * 16 * TN + (CX ? 1 : 2) * (lane & 15);
 
-    f64x2 ra[NA], rb[NB];
+    // two staging register sets: the data of global stage s waits in set s & 1, so a load has
+    // two stages (not one) to arrive from HBM before it is written to LDS
+    f64x2 ra[2][NA], rb[2][NB];
 
     // load the cursor's stage into registers and advance the cursor (to the
     // next tile of this workgroup after the last k-stage)
-    auto fetch = [&]() {
+    auto fetch = [&](auto set_c) {
+        constexpr int set = decltype(set_c)::value;
 #pragma unroll
         for (int i = 0; i < NA; ++i) {
-            ra[i] = load16(a_ptr[i], voff_a);
+            ra[set][i] = load16(a_ptr[i], voff_a);
             a_ptr[i] += a_step;
         }
 #pragma unroll
         for (int i = 0; i < NB; ++i) {
-            rb[i] = load16(b_ptr[i], voff_b);
+            rb[set][i] = load16(b_ptr[i], voff_b);
             b_ptr[i] += b_step;
         }
         if (++f_k == nk) {
@@ -185,20 +188,20 @@ void gemm_fast_kernel(const FastArgs g) {
         }
     };
 
-    auto stash = [&](auto buf_c) {
+    auto stash = [&](auto buf_c) {   // stage data of parity `buf` -> LDS stage `buf`
         constexpr int buf = decltype(buf_c)::value;
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int i = 0; i < NA; ++i) {
             double* d = st_a + buf * A_STAGE + i * 32 * SA;
-            if constexpr (CX) { d[0] = ra[i][0]; d[BM * SA] = ra[i][1]; }
-            else *reinterpret_cast<f64x2*>(d) = ra[i];
+            if constexpr (CX) { d[0] = ra[buf][i][0]; d[BM * SA] = ra[buf][i][1]; }
+            else *reinterpret_cast<f64x2*>(d) = ra[buf][i];
         }
 #pragma unroll
         for (int i = 0; i < NB; ++i) {
             double* d = st_b + buf * B_STAGE + i * RPS * SB;
-            if constexpr (CX) { d[0] = rb[i][0]; d[KT * SB] = rb[i][1]; }
-            else *reinterpret_cast<f64x2*>(d) = rb[i];
+            if constexpr (CX) { d[0] = rb[buf][i][0]; d[KT * SB] = rb[buf][i][1]; }
+            else *reinterpret_cast<f64x2*>(d) = rb[buf][i];
         }
     };
 
@@ -291,11 +294,12 @@ void gemm_fast_kernel(const FastArgs g) {
     const unsigned my_tiles = (g.total - blockIdx.x + P - 1) / P;
     const int64_t stages = (int64_t)my_tiles * nk;
 
-    fetch();
+    fetch(B0{});                       // global stage 0
     stash(B0{});
     __syncthreads();
     double a0[NP][TM], b0[NP][TN], a1[NP][TM], b1[NP][TN];
-    if (f_valid) fetch();
+    if (f_valid) fetch(B1{});          // stage 1
+    if (f_valid) fetch(B0{});          // stage 2
     read_frags(B0{}, 0, a0, b0);
 
     unsigned c_v = blockIdx.x;   // virtual block being computed
@@ -319,9 +323,9 @@ void gemm_fast_kernel(const FastArgs g) {
             else               { read_frags(cur_c, kk + 1, a0, b0); __builtin_amdgcn_sched_barrier(0); mfma_step(a1, b1, F_{}); }
             __builtin_amdgcn_sched_barrier(0);
         }
-        if (has_next) stash(NXT{});
+        if (has_next) stash(NXT{});        // stage gs+1, loaded two stages ago
         __syncthreads();
-        if (f_valid) fetch();
+        if (f_valid) fetch(NXT{});         // stage gs+3 into the set just written out
         if (has_next) read_frags(NXT{}, 0, a0, b0);
         __builtin_amdgcn_sched_barrier(0);
         mfma_step(a1, b1, F_{});
@@ -375,13 +379,24 @@ static int launch_fast(const double* A, const double* B, double* C, int64_t m, i
     }
     int64_t P = 2 * (int64_t)n_cu;
     P -= P % 8;
-    // Persistent walking pays on short tile lists (fewer launch gaps, cross-tile prefetch:
-    // +7 % at l = 64); on long lists the static split loses more to uneven CU progress than
-    // the prefetch wins (-4 % at l = 256, profiles/r01_gemm_notes.txt), so those keep one
-    // workgroup per tile and let the dispatcher balance.  g_gemm_fast_persist: 0 never,
-    // 1 automatic, 2 always.
-    const bool persist = g_gemm_fast_persist == 2 || (g_gemm_fast_persist == 1 && total <= 8 * P);
-    if (!persist || total <= P) P = total;
+    // How many tiles a workgroup walks (cross-tile prefetch hides the next tile's first loads
+    // behind the current tile's last stages and epilogue):
+    //   short tile lists (<= 8 per resident workgroup): fully persistent grid, +7 % at l = 64;
+    //   long lists: 4 tiles per workgroup -- the dispatcher keeps balancing the grid, which a
+    //   static split of a long list loses more on than the prefetch wins (-4 % at l = 256 when
+    //   fully persistent, +1.5 % with 4 tiles; profiles/r01_gemm_notes.txt).
+    // g_gemm_fast_persist: 0 one tile per workgroup, 1 this policy, 2 always fully
+    // persistent, >= 3 that many tiles per workgroup.
+    int64_t tiles_per_wg = 1;
+    bool full = false;
+    if (g_gemm_fast_persist == 1) { full = total <= 8 * P; tiles_per_wg = 4; }
+    else if (g_gemm_fast_persist == 2) full = true;
+    else if (g_gemm_fast_persist >= 3) tiles_per_wg = g_gemm_fast_persist;
+    if (!full) {
+        P = (total + tiles_per_wg - 1) / tiles_per_wg;
+        P = (P + 7) & ~int64_t(7);
+    }
+    if (P > total) P = total;
     const size_t lds = sizeof(double) * 2 * NP * (BM * (KT + 2) + KT * (CX ? BN + 16 : BN));
     auto kern = gemm_fast_kernel<CX, TM, TN>;
     static bool lds_opt_in = false;
