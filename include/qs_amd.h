@@ -165,6 +165,18 @@ int qs_spin_squared_two_body(const void* S, void* out, int64_t n, int64_t p_lo,
                              int64_t p_hi, int antisymmetrize, void* stream);
 
 /*
+ * Coulomb matrix elements of the two-dimensional harmonic oscillator (quantum
+ * dot) in the Fock-Darwin basis, omega = 1:
+ *   out[p - p_lo, q, r, s] = <pq|u|rs>,  p in [p_lo, p_hi),  out : fp64
+ * orbitals ordered by shell as two_dim_helper.py:111-166 (index p <-> (n, m)).
+ * Replaces _get_coulomb_elements, quantum_dots/two_dim/two_dim_helper.py:250-268
+ * and coulomb_ho, quantum_dots/two_dim/coulomb_elements.py:6-92 (the input
+ * generator of TwoDimensionalHarmonicOscillator, two_dim_ho.py:84-95).
+ */
+int qs_tdho_coulomb_elements(void* out, int64_t l, int64_t p_lo, int64_t p_hi,
+                             void* stream);
+
+/*
  * Auxiliary entry points (no reference counterpart).
  *   qs_tuning_set: override a kernel choice for tuning runs; keys
  *     "gemm_f64_cfg", "gemm_c128_cfg" (tile shape of the general

@@ -19,9 +19,11 @@ from .general_orbital_system import GeneralOrbitalSystem
 from .random_basis import RandomBasisSet
 from .spatial_orbital_system import SpatialOrbitalSystem
 from .system import QuantumSystem
+from .two_dim_ho import TwoDimensionalHarmonicOscillator
 
 __all__ = [
     "BasisSet", "RandomBasisSet", "QuantumSystem", "SpatialOrbitalSystem",
     "GeneralOrbitalSystem", "setup_basis_set", "construct_custom_system",
+    "TwoDimensionalHarmonicOscillator",
     "hip", "DeviceModule", "DeviceArray", "kernels", "sharded",
 ]

@@ -282,10 +282,52 @@ def case_change_basis_with_spf():
     )
 
 
+def case_tdho_coulomb():
+    """2-D harmonic-oscillator Coulomb elements: (i) the reference's own table of
+    elements (tests/dat/two_dim_quantum_dots_coulomb_elements.dat, orbitals 0..35,
+    ~8 significant digits, used by its tests with atol 1e-6) repacked as arrays --
+    data, not source; (ii) elements computed here by the reference's coulomb_ho in
+    interpreter mode (numba absent), incl. the high shells of the l=55 basis; (iii) its
+    index map and shell energies."""
+    from quantum_systems.quantum_dots.two_dim.coulomb_elements import coulomb_ho
+    from quantum_systems.quantum_dots.two_dim.two_dim_helper import (
+        get_indices_nm, get_one_body_elements,
+    )
+
+    rows = np.loadtxt("/root/reference/tests/dat/two_dim_quantum_dots_coulomb_elements.dat")
+    save("tdho_coulomb_table", idx=rows[:, :4].astype(np.uint8), val=rows[:, 4])
+    nm = np.array([get_indices_nm(p) for p in range(66)], dtype=np.int64)
+    rng = np.random.default_rng(2)
+    picks = []
+    # m-conserving index quadruples: low shells exhaustively sampled, high shells sparsely
+    while len(picks) < 60:
+        hi = 55 if len(picks) >= 40 else 21
+        p, q, r = rng.integers(0, hi, size=3)
+        target = nm[p, 1] + nm[q, 1] - nm[r, 1]
+        cand = [s for s in range(hi) if nm[s, 1] == target]
+        if not cand:
+            continue
+        s = int(rng.choice(cand))
+        if len(picks) >= 40 and max(nm[p, 0], nm[q, 0], nm[r, 0], nm[s, 0]) > 2:
+            continue  # keep the interpreted evaluation to seconds per element
+        picks.append((p, q, r, s))
+    picks = np.array(picks, dtype=np.int64)
+    vals = np.array([
+        coulomb_ho(nm[p, 0], nm[p, 1], nm[q, 0], nm[q, 1], nm[r, 0], nm[r, 1], nm[s, 0], nm[s, 1])
+        for p, q, r, s in picks
+    ])
+    save("tdho_coulomb_spot", idx=picks, val=vals, index_map=nm,
+         one_body_l55=np.diag(get_one_body_elements(55)))
+
+
 if __name__ == "__main__":
+    if len(sys.argv) > 1 and sys.argv[1] == "tdho":
+        case_tdho_coulomb()
+        sys.exit(0)
     case_transforms()
     case_spin_statics()
     case_random_basis_stream()
     case_config1()
     case_gos_small()
     case_change_basis_with_spf()
+    case_tdho_coulomb()
