@@ -117,33 +117,57 @@ void gemm_kernel(const GemmArgs g) {
     typedef typename std::conditional<SCALAR, double, f64x2>::type item_t;
     item_t ra[NA], rb[NB];
 
-    // Branch-free staging.  fetch() only issues loads: an out-of-range item
-    // reads element 0 of its operand (always valid memory).  stash() zeroes those
-    // items and writes the stage to LDS; it sits behind a scheduling fence so
-    // that neither the zeroing selects nor the wait for the loads can drift up
-    // in front of the MFMAs that are meant to cover the load latency.
+    // Staging.  Rows of A beyond m and columns of B beyond n only feed output rows / columns
+    // that are never stored (an MFMA output row depends on its own A row only, a column on its
+    // own B column), so those loads are simply CLAMPED to the last valid row / column: no
+    // zero fill, no per-stage address arithmetic -- each item is one base pointer (set up
+    // once) plus a uniform step.  Only the K edge needs zeros, and only in the final stage of
+    // a K that is not a multiple of KT: that stage takes the masked variants.  stash() sits
+    // behind a scheduling fence so that the wait for the loads cannot drift up in front of
+    // the MFMAs that cover their latency.
+    constexpr int VW = (SCALAR || CX) ? 1 : 2;   // elements per staged item
+    const double* pa[NA];
+    const double* pb[NB];
+    int kca[NA], krb[NB];
+#pragma unroll
+    for (int i = 0; i < NA; ++i) {
+        const int c = tid + i * NT;
+        const int row = min(m0 + c / IPR_A, M - 1);
+        kca[i] = (c % IPR_A) * VW;
+        pa[i] = A + ((int64_t)row * g.lda + kca[i]) * ES;
+    }
+#pragma unroll
+    for (int i = 0; i < NB; ++i) {
+        const int c = tid + i * NT;
+        krb[i] = c / IPR_B;
+        const int col = min(n0 + (c % IPR_B) * VW, N - VW);
+        pb[i] = B + ((int64_t)krb[i] * g.ldb + col) * ES;
+    }
+    const int64_t b_kstep = g.ldb * ES;          // doubles per unit of k in B
+
     auto fetch = [&](int k0) {
+        if (k0 + KT <= K) {
 #pragma unroll
-        for (int i = 0; i < NA; ++i) {
-            const int c = tid + i * NT;
-            const int row = c / IPR_A;
-            const int kc = (c % IPR_A) * ((SCALAR || CX) ? 1 : 2);
-            const int gr = m0 + row, gk = k0 + kc;
-            const bool ok = gr < M && gk < K;
-            const double* p = A + (ok ? ((int64_t)gr * g.lda + gk) * ES : 0);
-            if constexpr (SCALAR) ra[i] = *p;
-            else ra[i] = *reinterpret_cast<const f64x2*>(p);
-        }
+            for (int i = 0; i < NA; ++i) {
+                const double* p = pa[i] + (int64_t)k0 * ES;
+                if constexpr (SCALAR) ra[i] = *p; else ra[i] = *reinterpret_cast<const f64x2*>(p);
+            }
 #pragma unroll
-        for (int i = 0; i < NB; ++i) {
-            const int c = tid + i * NT;
-            const int row = c / IPR_B;
-            const int nc = (c % IPR_B) * ((SCALAR || CX) ? 1 : 2);
-            const int gk = k0 + row, gn = n0 + nc;
-            const bool ok = gk < K && gn < N;
-            const double* p = B + (ok ? ((int64_t)gk * g.ldb + gn) * ES : 0);
-            if constexpr (SCALAR) rb[i] = *p;
-            else rb[i] = *reinterpret_cast<const f64x2*>(p);
+            for (int i = 0; i < NB; ++i) {
+                const double* p = pb[i] + k0 * b_kstep;
+                if constexpr (SCALAR) rb[i] = *p; else rb[i] = *reinterpret_cast<const f64x2*>(p);
+            }
+        } else {   // K edge: keep every address inside the operand (the values are zeroed in stash)
+#pragma unroll
+            for (int i = 0; i < NA; ++i) {
+                const double* p = pa[i] + (int64_t)((k0 + kca[i] < K) ? k0 : 0) * ES - (k0 + kca[i] < K ? 0 : kca[i] * ES);
+                if constexpr (SCALAR) ra[i] = *p; else ra[i] = *reinterpret_cast<const f64x2*>(p);
+            }
+#pragma unroll
+            for (int i = 0; i < NB; ++i) {
+                const double* p = pb[i] + ((k0 + krb[i] < K) ? k0 : -krb[i]) * b_kstep;
+                if constexpr (SCALAR) rb[i] = *p; else rb[i] = *reinterpret_cast<const f64x2*>(p);
+            }
         }
     };
 
@@ -151,33 +175,30 @@ void gemm_kernel(const GemmArgs g) {
         __builtin_amdgcn_sched_barrier(0);
         double* as = As + buf * A_STAGE;
         double* bs = Bs + buf * B_STAGE;
+        const bool edge = k0 + KT > K;
 #pragma unroll
         for (int i = 0; i < NA; ++i) {
             const int c = tid + i * NT;
-            const int row = c / IPR_A;
-            const int kc = (c % IPR_A) * ((SCALAR || CX) ? 1 : 2);
-            const bool ok = (m0 + row) < M && (k0 + kc) < K;
-            double* d = as + row * SA + kc;
-            if constexpr (SCALAR) *d = ok ? ra[i] : 0.0;
-            else {
-                const f64x2 v = ok ? ra[i] : f64x2{0.0, 0.0};
-                if constexpr (CX) { d[0] = v[0]; d[BM * SA] = v[1]; }
-                else *reinterpret_cast<f64x2*>(d) = v;
+            double* d = as + (c / IPR_A) * SA + kca[i];
+            item_t v = ra[i];
+            if (edge && k0 + kca[i] >= K) {
+                if constexpr (SCALAR) v = 0.0; else v = f64x2{0.0, 0.0};
             }
+            if constexpr (SCALAR) *d = v;
+            else if constexpr (CX) { d[0] = v[0]; d[BM * SA] = v[1]; }
+            else *reinterpret_cast<f64x2*>(d) = v;
         }
 #pragma unroll
         for (int i = 0; i < NB; ++i) {
             const int c = tid + i * NT;
-            const int row = c / IPR_B;
-            const int nc = (c % IPR_B) * ((SCALAR || CX) ? 1 : 2);
-            const bool ok = (k0 + row) < K && (n0 + nc) < N;
-            double* d = bs + row * SB + nc;
-            if constexpr (SCALAR) *d = ok ? rb[i] : 0.0;
-            else {
-                const f64x2 v = ok ? rb[i] : f64x2{0.0, 0.0};
-                if constexpr (CX) { d[0] = v[0]; d[KT * SB] = v[1]; }
-                else *reinterpret_cast<f64x2*>(d) = v;
+            double* d = bs + krb[i] * SB + (c % IPR_B) * VW;
+            item_t v = rb[i];
+            if (edge && k0 + krb[i] >= K) {
+                if constexpr (SCALAR) v = 0.0; else v = f64x2{0.0, 0.0};
             }
+            if constexpr (SCALAR) *d = v;
+            else if constexpr (CX) { d[0] = v[0]; d[KT * SB] = v[1]; }
+            else *reinterpret_cast<f64x2*>(d) = v;
         }
     };
 
