@@ -69,6 +69,14 @@ class HipEngine:
     def partial(u_slab, C, C_tilde):
         return kernels.transform_two_body_partial(u_slab, C, C_tilde)
 
+    @staticmethod
+    def gemm_strided(dt, A, B, out, m, n, k, lda, ldb, ldc, batch=1, sa=0, sb=0, sc=0,
+                     accumulate=False, a_off=0, b_off=0, c_off=0):
+        """Batched product on sub-blocks of larger buffers (offsets, leading
+        dimensions and batch strides in elements) -- ``qs_matmul`` as is."""
+        return kernels.gemm_raw(dt, A, B, out, m, n, k, lda, ldb, ldc, batch, sa, sb, sc,
+                                accumulate, a_off, b_off, c_off)
+
 
 def _bra(C, C_tilde):
     return kernels.default_bra(C) if C_tilde is None else C_tilde
@@ -185,3 +193,74 @@ def transform_two_body_sharded(u_bslab, C, C_tilde=None, rank=0, world=1, group=
         engine.matmul(Ct[:, g_lo:g_hi].contiguous(), recv_blocks[g], out=out, accumulate=not first)
         first = False
     return out.reshape(pc, M, M, M)
+
+
+def transform_two_body_sharded_inplace(u_bslab, C, C_tilde=None, rank=0, world=1, group=None,
+                                       engine=HipEngine, staging_rows=1):
+    """Memory-lean form of ``transform_two_body_sharded`` for tensors that only
+    just fit the node (BASELINE.json configs[4]: l = 512 complex128, 137 GB per
+    GPU at G = 8).  Square transforms with ``l`` divisible by ``world`` only.
+
+    ``u_bslab = u[:, b_lo:b_hi]`` is DESTROYED: it is first overwritten, one
+    ``b`` at a time, by ``X[p, b, r, s] = Ct[p,a] u[a,b,c,d] C[c,r] C[d,s]`` (three
+    l^3-sized temporaries), then exchanged IN PLACE with the peers through a
+    small staging buffer -- the block of rows owned by peer g is swapped for the
+    block peer g holds for us, ``staging_rows`` rows per collective -- and
+    finally contracted over b into the freshly allocated result slab.  Peak
+    memory: input slab + output slab + O(l^3).  Same arithmetic as the
+    out-of-place layout, same single exchange step (chunked).
+    """
+    Ct = _bra(C, C_tilde)
+    L, M = C.shape
+    if L != M or L % world:
+        raise ValueError("the in-place layout needs a square transform and l divisible by world")
+    bl = L // world           # b (and p) rows per rank
+    pc = bl
+    if tuple(u_bslab.shape) != (L, bl, L, L) or not u_bslab.is_contiguous():
+        raise ValueError(f"rank {rank}: expected a contiguous slab of shape {(L, bl, L, L)}")
+    dt = kernels.result_dtype(u_bslab, C, Ct)
+    if u_bslab.dtype != dt:
+        raise ValueError("the slab must already have the result dtype (it is overwritten in place)")
+    C, Ct = C.to(dt).contiguous(), Ct.to(dt).contiguous()
+    CT = C.transpose(0, 1).contiguous()
+    dev = u_bslab.device
+    L2, L3 = L * L, L * L * L
+
+    # ---- local phase, one b at a time:  u[:, j] -> X[:, j]
+    t1 = torch.empty((L, L, L), dtype=dt, device=dev)
+    t2 = torch.empty((L, L, L), dtype=dt, device=dev)
+    for j in range(bl):
+        # d:  t1[a][c, s] = u[a, j][c, d] C[d, s]            batch over a, A strided by bl*L^2
+        engine.gemm_strided(dt, u_bslab, C, t1, L, L, L, L, L, L, batch=L, sa=bl * L2, sb=0, sc=L2,
+                            a_off=j * L2)
+        # c:  t2[a][r, s] = CT[r, c] t1[a][c, s]
+        engine.gemm_strided(dt, CT, t1, t2, L, L, L, L, L, L, batch=L, sa=0, sb=L2, sc=L2)
+        # a:  X[p, j][(r, s)] = Ct[p, a] t2[a][(r, s)]       written over u[:, j] (row stride bl*L^2)
+        engine.gemm_strided(dt, Ct, t2, u_bslab, L, L2, L, L, L2, bl * L2, c_off=j * L2)
+    del t1, t2
+    x = u_bslab               # now X[p, b_loc, r, s]
+
+    # ---- exchange in place: rows p in slab(g) <-> what peer g holds for our rows
+    if world > 1:
+        width = 2 if dt.is_complex else 1
+        row = bl * L2 * width                       # float64 words per p row of X
+        xf = _as_real_flat(x)                       # view
+        rows = max(1, min(int(staging_rows), pc))
+        send = torch.empty(world * rows * row, dtype=torch.float64, device=dev)
+        recv = torch.empty_like(send)
+        for r0 in range(0, pc, rows):
+            nr = min(rows, pc - r0)
+            for g in range(world):
+                src = xf[(g * pc + r0) * row: (g * pc + r0 + nr) * row]
+                send[g * nr * row: (g + 1) * nr * row] = src
+            dist.all_to_all_single(recv[: world * nr * row], send[: world * nr * row], group=group)
+            for g in range(world):
+                xf[(g * pc + r0) * row: (g * pc + r0 + nr) * row] = recv[g * nr * row: (g + 1) * nr * row]
+        del send, recv
+
+    # ---- b:  out[p][q, (r,s)] = sum_g Ct[q, b in slab(g)] X_g[p][b, (r,s)]   (zero-copy views of x)
+    out = torch.empty((pc, L, L2), dtype=dt, device=dev)
+    xv = x.reshape(world, pc, bl, L2)
+    for g in range(world):
+        engine.matmul(Ct[:, g * bl:(g + 1) * bl].contiguous(), xv[g], out=out, accumulate=g > 0)
+    return out.reshape(pc, L, L, L)

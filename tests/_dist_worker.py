@@ -35,6 +35,24 @@ class OracleEngine:
         return out
 
     @staticmethod
+    def gemm_strided(dt, A, B, out, m, n, k, lda, ldb, ldc, batch=1, sa=0, sb=0, sc=0,
+                     accumulate=False, a_off=0, b_off=0, c_off=0):
+        # strided views over the flat storage, exactly the addressing qs_matmul uses
+        def view(t, off, rows, cols, ld, stride):
+            flat = t.reshape(-1)
+            return torch.as_strided(flat, (batch, rows, cols), (stride, ld, 1), storage_offset=off)
+
+        a = view(A, a_off, m, k, lda, sa).numpy()
+        b = view(B, b_off, k, n, ldb, sb).numpy()
+        res = torch.from_numpy(np.matmul(a, b))
+        c = view(out, c_off, m, n, ldc, sc)
+        if accumulate:
+            c += res
+        else:
+            c.copy_(res)
+        return out
+
+    @staticmethod
     def partial(u_slab, C, Ct):
         v = orc.transform_two_body_dcb(
             u_slab.numpy(), C.resolve_conj().numpy(), Ct.resolve_conj().numpy()
@@ -46,7 +64,7 @@ def main():
     dist.init_process_group("gloo")
     rank, world = dist.get_rank(), dist.get_world_size()
     rng = np.random.default_rng(42)  # same stream on every rank
-    for (L, M, cplx) in [(6, 6, True), (7, 5, False), (5, 9, True), (3, 3, False)]:
+    for (L, M, cplx) in [(6, 6, True), (7, 5, False), (5, 9, True), (3, 3, False), (12, 12, False)]:
         if cplx:
             u = rng.random((L,) * 4) + 1j * rng.random((L,) * 4)
             C = rng.random((L, M)) + 1j * rng.random((L, M))
@@ -70,6 +88,14 @@ def main():
         ub = tu[:, b_lo:b_hi].contiguous()
         slab2 = sharded.transform_two_body_sharded(ub, tC, tCt, rank, world, engine=OracleEngine)
         np.testing.assert_allclose(slab2.numpy(), ref[p_lo:p_hi], rtol=1e-12, atol=1e-12)
+
+        # layout 3: in-place, memory-lean form (square transforms, l divisible by world)
+        if L == M and L % world == 0:
+            for rows in (1, 2):
+                ub2 = tu[:, b_lo:b_hi].contiguous().clone()
+                slab4 = sharded.transform_two_body_sharded_inplace(
+                    ub2, tC, tCt, rank, world, engine=OracleEngine, staging_rows=rows)
+                np.testing.assert_allclose(slab4.numpy(), ref[p_lo:p_hi], rtol=1e-12, atol=1e-12)
 
         # default bra (C^dagger) path
         slab3 = sharded.transform_two_body_sharded(ub, tC, None, rank, world, engine=OracleEngine)
