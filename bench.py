@@ -397,7 +397,7 @@ def main():
             pass
 
     probes = {}
-    if not args.no_probes:
+    if not args.no_probes and world == 1:   # single-GPU ceilings; at N > 1 the other ranks would only wait
         st = torch.cuda.current_stream().cuda_stream
         blocks, iters = 256 * 8, 4000
         sink = torch.zeros(1 + 2 * blocks, dtype=torch.int64, device=device)
@@ -437,7 +437,7 @@ def main():
         "parity": {"randomised_identity_rel_diff": rel, "bound": 1e-10},
         "probes": probes,
     }
-    if not args.no_cpu_baseline:
+    if not args.no_cpu_baseline and world == 1:   # reported at N = 1 only (rank 0 would stall the others)
         del res
         line["cpu_baseline"] = cpu_baseline(args.cpu_l)
     print(json.dumps(line), flush=True)
