@@ -231,14 +231,20 @@ def antisymmetrize(u, out=None):
     if src.dim() < 2 or src.shape[-2] != l:
         raise ValueError("last two axes must be square")
     npq = src.numel() // (l * l)
+    in_place = out is u
     if out is None:
         out = torch.empty_like(src)
-    elif out is u:
-        out = src
+    elif in_place:
+        out = src          # the kernel's tile-pair scheme is safe in place
+    elif out.dtype != dt or tuple(out.shape) != tuple(src.shape) or not out.is_contiguous():
+        raise ValueError("bad output buffer")
     check(
         lib.qs_antisymmetrize(dtype_code(dt), src.data_ptr(), out.data_ptr(), npq, l, _stream()),
         "qs_antisymmetrize",
     )
+    if in_place and src is not u:
+        u.copy_(src)       # `u` was a view / other dtype: write the result back into it
+        return u
     return out
 
 
