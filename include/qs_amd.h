@@ -181,8 +181,11 @@ int qs_tdho_coulomb_elements(void* out, int64_t l, int64_t p_lo, int64_t p_hi,
  *   qs_tuning_set: override a kernel choice for tuning runs; keys
  *     "gemm_f64_cfg", "gemm_c128_cfg" (tile shape of the general
  *     kernel, 0 = automatic), "gemm_pipe" (1 = rotated K-loop schedule, 0 = plain),
- *     "gemm_fast" (0 = never use the exact-tiling kernel), "gemm_fast_persist"
- *     (0 one workgroup per tile, 1 automatic, 2 always persistent),
+ *     "gemm_fast" (0 = general kernel only, 1 = automatic, 2 = exact form of
+ *     the VALU-free kernel only, 3 = its edge form wherever it is legal), "gemm_fast_shape" (edge-form tile
+ *     shape 1..4, 0 = automatic), "gemm_fast_persist"
+ *     (0 one workgroup per tile, 1 automatic, 2 always persistent, >= 3 tiles
+ *     per workgroup),
  *     "gemm_skinny" (0 = never use the streaming short-and-wide kernel).
  *   qs_probe_mfma_f64: register-resident fp64 MFMA loop, `blocks` workgroups
  *     of 4 waves, each wave issuing iters*8 v_mfma_f64_16x16x4_f64

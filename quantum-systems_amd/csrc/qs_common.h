@@ -42,7 +42,7 @@ int gemm_c128(const double* A, const double* B, double* C, int64_t m, int64_t n,
               int64_t k, int64_t lda, int64_t ldb, int64_t ldc, int64_t batch,
               int64_t sa, int64_t sb, int64_t sc, int accumulate, hipStream_t stream);
 
-// Exact-tiling fast path (qs_gemm_fast.hip): QS_OK / error after launching, 1 = not eligible.
+// VALU-free fast path, exact and edge forms (qs_gemm_fast.hip): QS_OK / error after launching, 1 = not eligible.
 int gemm_fast_try(int dtype, const double* A, const double* B, double* C, int64_t m, int64_t n,
                   int64_t k, int64_t lda, int64_t ldb, int64_t ldc, int64_t batch, int64_t sa,
                   int64_t sb, int64_t sc, int accumulate, int group_along_m, hipStream_t stream);
@@ -72,6 +72,7 @@ extern int g_gemm_c128_cfg;
 extern int g_gemm_pipe;
 extern int g_gemm_fast;
 extern int g_gemm_fast_persist;
+extern int g_gemm_fast_shape;
 extern int g_gemm_skinny;
 
 }  // namespace qs

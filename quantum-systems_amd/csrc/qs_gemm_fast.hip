@@ -1,19 +1,30 @@
-// Exact-tiling fast path of the batched row-major product (see qs_gemm.hip
-// for the general kernel and the contraction -> GEMM map).
+// Fast path of the batched row-major product (see qs_gemm.hip for the general
+// kernel and the contraction -> GEMM map).
 //
 // Why a second kernel: on gfx950 the fp64 MFMA shares the SIMD's vector issue
 // with ordinary VALU work -- every VALU instruction in the K loop takes its
 // issue cycles away from the matrix pipe (measured with tools/probe_mix.hip:
 // 32 integer adds per 16 MFMAs cost 12 % of the MFMA rate, and two co-resident
 // waves do not hide it).  The general kernel spends ~130 VALU instructions per
-// K step on 64-bit address arithmetic and edge handling.  This kernel is for
-// products whose extents are whole multiples of the tile (l = 128, 256, 512,
-// ...); its K loop contains no VALU work at all:
-//   * global loads use the scalar-base form (SGPR pointer + one loop-invariant
-//     32-bit lane offset); the per-row bases advance on the scalar ALU;
+// K step on 64-bit address arithmetic and edge handling.  The K loop of this
+// kernel contains no VALU work at all:
+//   * global loads use the scalar-base form (SGPR buffer descriptor + one
+//     loop-invariant 32-bit lane offset); the bases advance on the scalar ALU;
 //   * LDS addresses are one VGPR + immediates (the loop is unrolled by two so
 //     the stage buffer is a compile-time constant);
-//   * no bounds checks, no zero fill.
+//   * no per-lane bounds checks.
+// Two forms (template parameter EDGE):
+//   * exact: every extent a whole multiple of the tile (l = 128, 256, 512, ...);
+//   * edge: any extent.  Memory safety comes from the buffer descriptors
+//     (num_records = bytes left in the operand, kept on the scalar ALU; the
+//     hardware returns 0 for dwords past it), exactness from zeroing the
+//     k >= K part of the LAST k-stage in registers before it is written to
+//     LDS (selects, so stray non-finite values cannot leak), and the epilogue
+//     of a border tile stores under a per-lane predicate.  Rows >= m and
+//     columns >= n of a border tile multiply whatever the loads returned and
+//     are never stored.
+// VEC = 16-byte global accesses (even extents and strides, 16-byte aligned
+// bases), otherwise 8-byte ones (odd l, e.g. the 55 orbitals of config 2).
 //
 // Persistent workgroups: 2 per CU, each walks its share of the tile list
 // (virtual block ids bid, bid + P, bid + 2P, ... of the XCD-chunked order the
@@ -44,7 +55,10 @@ struct FastArgs {
     double* C;
     int64_t lda, ldb, ldc;   // elements
     int64_t sa, sb, sc;      // elements
-    int nk;                  // K / KT
+    uint64_t a_end, b_end;   // address one past the last byte of each operand (edge form)
+    int64_t m;               // extents (edge form: epilogue predicate, k-tail)
+    int n, k;
+    int nk;                  // ceil(K / KT)
     int tiles_m, tiles_n;
     unsigned total;          // tiles_m * tiles_n * batch = size of the virtual grid
     int group_along_m;
@@ -67,18 +81,43 @@ __device__ __forceinline__ uint64_t uniform64(uint64_t x) {
     return ((uint64_t)hi << 32) | lo;
 }
 
-// 16-byte load at scalar base + 32-bit lane offset (buffer form, no range limit in use)
-__device__ __forceinline__ f64x2 load16(uint64_t base, unsigned lane_off) {
-    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-    const auto rsrc = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void*>(base), (short)0,
-                                                        (int)0xFFFFFFFF, 0x00020000);
-    const u32x4 raw = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)lane_off, 0, 0);
-    return __builtin_bit_cast(f64x2, raw);
+// One global item (16 or 8 bytes) at scalar base + 32-bit lane offset, buffer form:
+// dwords at lane offsets >= `room` come back as 0 (raw buffer range check).
+template <bool V16>
+struct FastItem;
+template <>
+struct FastItem<true> {
+    typedef f64x2 type;
+    static __device__ __forceinline__ type load(uint64_t base, unsigned room, unsigned lane_off) {
+        typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+        const auto rsrc = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void*>(base), (short)0,
+                                                            (int)room, 0x00020000);
+        const u32x4 raw = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)lane_off, 0, 0);
+        return __builtin_bit_cast(f64x2, raw);
+    }
+};
+template <>
+struct FastItem<false> {
+    typedef double type;
+    static __device__ __forceinline__ type load(uint64_t base, unsigned room, unsigned lane_off) {
+        typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+        const auto rsrc = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void*>(base), (short)0,
+                                                            (int)room, 0x00020000);
+        const u32x2 raw = __builtin_amdgcn_raw_buffer_load_b64(rsrc, (int)lane_off, 0, 0);
+        return __builtin_bit_cast(double, raw);
+    }
+};
+
+// bytes from p to end, saturated to 32 bits (scalar ALU: both operands are wave-uniform)
+__device__ __forceinline__ unsigned bytes_left(uint64_t end, uint64_t p) {
+    const uint64_t d = end > p ? end - p : 0;
+    return d > 0xFFFFFFFFull ? 0xFFFFFFFFu : (unsigned)d;
 }
 
-template <bool CX, int TM, int TN>
+template <bool CX, int TM, int TN, bool VEC, bool EDGE>
 __global__ __launch_bounds__(256, 2)
 void gemm_fast_kernel(const FastArgs g) {
+    static_assert(!CX || VEC, "a complex element is one 16-byte item");
     constexpr int NP = CX ? 2 : 1;
     constexpr int ES = CX ? 2 : 1;
     constexpr int KT = CX ? 8 : 16;
@@ -88,16 +127,23 @@ void gemm_fast_kernel(const FastArgs g) {
     // B rows: complex fragments are ds_read_b64 (row stride = 16 mod 32 doubles is conflict-free);
     // fp64 fragments are ds_read_b128 column PAIRS (row stride = 0 mod 32 is conflict-free)
     constexpr int SA = KT + 2, SB = CX ? BN + 16 : BN;
-    constexpr int NA = BM * 8 / NT;                     // 16-byte items per thread, A stage (8 items per row)
-    constexpr int IPR_B = CX ? BN : BN / 2;             // 16-byte items per B row
-    static_assert(IPR_B % 64 == 0, "a wave must stay inside one B row");
-    constexpr int WPR = IPR_B / 64;                     // waves per B row
+    constexpr int EPI = (!CX && VEC) ? 2 : 1;           // tensor elements per global item
+    constexpr int DPI = CX ? 1 : EPI;                   // doubles per item inside one LDS plane
+    constexpr int IPR_A = KT / EPI;                     // items per A row of a stage
+    constexpr int RA = NT / IPR_A;                      // A rows covered by one item step
+    constexpr int NA = BM / RA;                         // items per thread, A stage
+    constexpr int IPR_B = BN / EPI;                     // items per B row
+    static_assert(NT % IPR_B == 0 && BM % RA == 0, "item steps cover whole rows");
     constexpr int RPS = NT / IPR_B;                     // B rows covered by one item step
-    constexpr int NB = KT * IPR_B / NT;
+    static_assert(KT % RPS == 0, "B item steps tile the stage");
+    constexpr int NB = KT / RPS;
     constexpr int A_STAGE = NP * BM * SA, B_STAGE = NP * KT * SB;
     constexpr size_t ESZ = 8 * ES;
+    constexpr unsigned IB = (unsigned)(EPI * ESZ);      // bytes per item
     static_assert(KS % 2 == 0, "fragment double buffering needs an even k-step count");
     static_assert(CX || TN % 2 == 0, "fp64 n-tiles come in column pairs");
+    using Item = FastItem<CX || VEC>;
+    using item_t = typename Item::type;
 
     extern __shared__ __attribute__((aligned(16))) double smem[];
     double* As = smem;
@@ -109,6 +155,8 @@ void gemm_fast_kernel(const FastArgs g) {
     const int wm = wave >> 1, wn = wave & 1;
     const int nk = g.nk;
     const unsigned P = gridDim.x;                       // persistent grid (multiple of 8 unless P == total)
+    // edge form: valid k-steps of a tile's last stage (KT when K is a whole number of stages)
+    const int k_tail = EDGE ? g.k - (nk - 1) * KT : KT;
 
     // tile coordinates of virtual block v
     auto decode = [&](unsigned v, int& m0, int& n0, int64_t& b) {
@@ -128,8 +176,8 @@ void gemm_fast_kernel(const FastArgs g) {
         n0 = __builtin_amdgcn_readfirstlane(nt) * BN;
     };
 
-    // ---- fetch cursor: scalar row bases of the tile being loaded + loop-invariant lane offsets
-    // Row bases are kept as scalar 64-bit integers and the loads go through buffer
+    // ---- fetch cursor: scalar bases of the tile being loaded + loop-invariant lane offsets
+    // The bases are kept as scalar 64-bit integers and the loads go through buffer
     // descriptors built from them: a descriptor lives in SGPRs by construction, which pins
     // the scalar-base addressing even though the bases are re-aimed at every tile change.
     uint64_t a_ptr[NA];
@@ -143,20 +191,24 @@ void gemm_fast_kernel(const FastArgs g) {
         const char* Ab = reinterpret_cast<const char*>(g.A + (b * g.sa + (int64_t)m0 * g.lda) * ES);
         const char* Bb = reinterpret_cast<const char*>(g.B + (b * g.sb + n0) * ES);
 #pragma unroll
-        for (int i = 0; i < NA; ++i) a_ptr[i] = uniform64(reinterpret_cast<uint64_t>(Ab + (size_t)i * 32 * g.lda * ESZ));
-        const int brow0 = wave / WPR;
+        for (int i = 0; i < NA; ++i) a_ptr[i] = uniform64(reinterpret_cast<uint64_t>(Ab + (size_t)i * RA * g.lda * ESZ));
+        // B rows: the wave's first row of an item step is part of the scalar base (no limit on
+        // ldb); only when a wave-instruction spans several rows (IPR_B < 64) does the lane
+        // offset carry a row term
+        const int brow0 = (wave * 64) / IPR_B;
 #pragma unroll
         for (int i = 0; i < NB; ++i) b_ptr[i] = uniform64(reinterpret_cast<uint64_t>(Bb + (size_t)(brow0 + i * RPS) * g.ldb * ESZ));
     };
     aim(f_v);
-    const unsigned voff_a = ((unsigned)(tid >> 3) * (unsigned)g.lda + (unsigned)(tid & 7) * (CX ? 1 : 2)) * (unsigned)ESZ;
-    const unsigned voff_b = (unsigned)(tid % IPR_B) * 16u;
+    const unsigned voff_a = (unsigned)(tid / IPR_A) * (unsigned)g.lda * (unsigned)ESZ + (unsigned)(tid % IPR_A) * IB;
+    const unsigned voff_b = (IPR_B < 64 ? (unsigned)(lane / IPR_B) * (unsigned)g.ldb * (unsigned)ESZ : 0u) +
+                            (unsigned)(tid % IPR_B) * IB;
     const size_t a_step = KT * ESZ;
     const size_t b_step = (size_t)KT * g.ldb * ESZ;
 
     // ---- LDS addressing: one base per operand and direction, the rest immediates
-    double* st_a = As + (tid >> 3) * SA + (tid & 7) * (CX ? 1 : 2);
-    double* st_b = Bs + (wave / WPR) * SB + (tid % IPR_B) * (CX ? 1 : 2);
+    double* st_a = As + (tid / IPR_A) * SA + (tid % IPR_A) * DPI;
+    double* st_b = Bs + (tid / IPR_B) * SB + (tid % IPR_B) * DPI;
     const double* rd_a = As + (wm * 16 * TM + (lane & 15)) * SA + (lane >> 4);
     // fp64: lane c of n-tile pair (2jp, 2jp+1) owns the ADJACENT columns 32jp + 2c, 32jp + 2c + 1,
     // so one 16-byte LDS read feeds two MFMA tiles and the epilogue stores 16 bytes per lane
@@ -164,7 +216,7 @@ void gemm_fast_kernel(const FastArgs g) {
 
     // two staging register sets: the data of global stage s waits in set s & 1, so a load has
     // two stages (not one) to arrive from HBM before it is written to LDS
-    f64x2 ra[2][NA], rb[2][NB];
+    item_t ra[2][NA], rb[2][NB];
 
     // load the cursor's stage into registers and advance the cursor (to the
     // next tile of this workgroup after the last k-stage)
@@ -172,12 +224,12 @@ void gemm_fast_kernel(const FastArgs g) {
         constexpr int set = decltype(set_c)::value;
 #pragma unroll
         for (int i = 0; i < NA; ++i) {
-            ra[set][i] = load16(a_ptr[i], voff_a);
+            ra[set][i] = Item::load(a_ptr[i], EDGE ? bytes_left(g.a_end, a_ptr[i]) : 0xFFFFFFFFu, voff_a);
             a_ptr[i] += a_step;
         }
 #pragma unroll
         for (int i = 0; i < NB; ++i) {
-            rb[set][i] = load16(b_ptr[i], voff_b);
+            rb[set][i] = Item::load(b_ptr[i], EDGE ? bytes_left(g.b_end, b_ptr[i]) : 0xFFFFFFFFu, voff_b);
             b_ptr[i] += b_step;
         }
         if (++f_k == nk) {
@@ -188,20 +240,43 @@ void gemm_fast_kernel(const FastArgs g) {
         }
     };
 
+    int s_k = 0;   // k-stage (inside its tile) of the next stage to be written to LDS
     auto stash = [&](auto buf_c) {   // stage data of parity `buf` -> LDS stage `buf`
         constexpr int buf = decltype(buf_c)::value;
         __builtin_amdgcn_sched_barrier(0);
+        if constexpr (EDGE) {
+            // last k-stage of a tile with a K tail: zero the k >= K part of both operands
+            const bool tail = (s_k == nk - 1) && (k_tail < KT);
+            if (++s_k == nk) s_k = 0;
+            if (tail) {
+                const item_t zero = item_t(0.0);
+#pragma unroll
+                for (int i = 0; i < NA; ++i) {
+                    if constexpr (EPI == 2) {
+                        if ((tid % IPR_A) * 2 >= k_tail) ra[buf][i][0] = 0.0;
+                        if ((tid % IPR_A) * 2 + 1 >= k_tail) ra[buf][i][1] = 0.0;
+                    } else {
+                        if ((tid % IPR_A) >= k_tail) ra[buf][i] = zero;
+                    }
+                }
+#pragma unroll
+                for (int i = 0; i < NB; ++i)
+                    if (tid / IPR_B + i * RPS >= k_tail) rb[buf][i] = zero;
+            }
+        }
 #pragma unroll
         for (int i = 0; i < NA; ++i) {
-            double* d = st_a + buf * A_STAGE + i * 32 * SA;
+            double* d = st_a + buf * A_STAGE + i * RA * SA;
             if constexpr (CX) { d[0] = ra[buf][i][0]; d[BM * SA] = ra[buf][i][1]; }
-            else *reinterpret_cast<f64x2*>(d) = ra[buf][i];
+            else if constexpr (VEC) *reinterpret_cast<f64x2*>(d) = ra[buf][i];
+            else d[0] = ra[buf][i];
         }
 #pragma unroll
         for (int i = 0; i < NB; ++i) {
             double* d = st_b + buf * B_STAGE + i * RPS * SB;
             if constexpr (CX) { d[0] = rb[buf][i][0]; d[KT * SB] = rb[buf][i][1]; }
-            else *reinterpret_cast<f64x2*>(d) = rb[buf][i];
+            else if constexpr (VEC) *reinterpret_cast<f64x2*>(d) = rb[buf][i];
+            else d[0] = rb[buf][i];
         }
     };
 
@@ -249,40 +324,70 @@ void gemm_fast_kernel(const FastArgs g) {
     };
 
     // epilogue of the tile at virtual block v: reg r of a lane -> row (lane>>4) + 4r of
-    // each 16-row block; 16 bytes per lane
-    auto epilogue = [&](unsigned v) {
+    // each 16-row block; 16 bytes per lane (8-byte pieces in the !VEC form).  `guard`:
+    // border tile of the edge form, rows >= m and columns >= n are not stored.
+    auto epilogue = [&](unsigned v) __attribute__((always_inline)) {
         int m0, n0; int64_t b;
         decode(v, m0, n0, b);
-        double* __restrict__ C = g.C + (b * g.sc + (int64_t)(m0 + wm * 16 * TM + (lane >> 4)) * g.ldc +
-                                        n0 + wn * 16 * TN + (CX ? 1 : 2) * (lane & 15)) * ES;
-        auto store_all = [&](auto add_c) {
+        const int64_t row_l = (int64_t)m0 + wm * 16 * TM + (lane >> 4);
+        const int col_l = n0 + wn * 16 * TN + (CX ? 1 : 2) * (lane & 15);
+        double* __restrict__ C = g.C + (b * g.sc + row_l * g.ldc + col_l) * ES;
+        auto store_all = [&](auto add_c, auto guard_c) __attribute__((always_inline)) {
             constexpr bool add = decltype(add_c)::value;
+            constexpr bool guard = decltype(guard_c)::value;
 #pragma unroll
             for (int i = 0; i < TM; ++i) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     double* crow = C + (int64_t)(i * 16 + 4 * r) * g.ldc * ES;
+                    const bool row_ok = !guard || row_l + i * 16 + 4 * r < g.m;
                     if constexpr (CX) {
 #pragma unroll
                         for (int j = 0; j < TN; ++j) {
-                            f64x2* dst = reinterpret_cast<f64x2*>(crow + 2 * j * 16);
-                            f64x2 v2 = f64x2{acc[0][i][j][r], acc[1][i][j][r]};
-                            if constexpr (add) v2 += *dst;
-                            *dst = v2;
+                            if (row_ok && (!guard || col_l + j * 16 < g.n)) {
+                                f64x2* dst = reinterpret_cast<f64x2*>(crow + 2 * j * 16);
+                                f64x2 v2 = f64x2{acc[0][i][j][r], acc[1][i][j][r]};
+                                if constexpr (add) v2 += *dst;
+                                *dst = v2;
+                            }
+                        }
+                    } else if constexpr (VEC) {
+#pragma unroll
+                        for (int jp = 0; jp < TN / 2; ++jp) {
+                            if (row_ok && (!guard || col_l + jp * 32 < g.n)) {   // n is even in this form
+                                f64x2* dst = reinterpret_cast<f64x2*>(crow + jp * 32);
+                                f64x2 v2 = f64x2{acc[0][i][2 * jp][r], acc[0][i][2 * jp + 1][r]};
+                                if constexpr (add) v2 += *dst;
+                                *dst = v2;
+                            }
                         }
                     } else {
 #pragma unroll
                         for (int jp = 0; jp < TN / 2; ++jp) {
-                            f64x2* dst = reinterpret_cast<f64x2*>(crow + jp * 32);
-                            f64x2 v2 = f64x2{acc[0][i][2 * jp][r], acc[0][i][2 * jp + 1][r]};
-                            if constexpr (add) v2 += *dst;
-                            *dst = v2;
+#pragma unroll
+                            for (int h = 0; h < 2; ++h) {
+                                if (row_ok && (!guard || col_l + jp * 32 + h < g.n)) {
+                                    double* dst = crow + jp * 32 + h;
+                                    double v1 = acc[0][i][2 * jp + h][r];
+                                    if constexpr (add) v1 += *dst;
+                                    *dst = v1;
+                                }
+                            }
                         }
                     }
                 }
             }
         };
-        if (g.accumulate) store_all(std::true_type{}); else store_all(std::false_type{});
+        const bool border = EDGE && ((int64_t)m0 + BM > g.m || n0 + BN > g.n);   // wave-uniform
+        if (border) {
+            if constexpr (EDGE) {
+                if (g.accumulate) store_all(std::true_type{}, std::true_type{});
+                else store_all(std::false_type{}, std::true_type{});
+            }
+        } else {
+            if (g.accumulate) store_all(std::true_type{}, std::false_type{});
+            else store_all(std::false_type{}, std::false_type{});
+        }
     };
 
     using B0 = std::integral_constant<int, 0>;
@@ -343,23 +448,31 @@ void gemm_fast_kernel(const FastArgs g) {
     }
 }
 
-int g_gemm_fast = 1;           // tuning knob: 0 routes everything through the general kernel
+int g_gemm_fast = 1;           // tuning knob: 0 general kernel only, 1 automatic, 2 exact form only, 3 edge form wherever legal
 int g_gemm_fast_persist = 1;   // tuning knob: 0 one workgroup per tile, 1 automatic, 2 always persistent
+int g_gemm_fast_shape = 0;     // tuning knob: forces edge-form shape 1..N (0 = by padded-work cost)
 
-template <bool CX, int TM, int TN>
+template <bool CX, int TM, int TN, bool VEC, bool EDGE>
 static int launch_fast(const double* A, const double* B, double* C, int64_t m, int64_t n, int64_t k,
                        int64_t lda, int64_t ldb, int64_t ldc, int64_t batch, int64_t sa, int64_t sb,
                        int64_t sc, int accumulate, int group_along_m, hipStream_t stream) {
     constexpr int KT = CX ? 8 : 16;
     constexpr int NP = CX ? 2 : 1;
     constexpr int BM = 32 * TM, BN = 32 * TN;
+    constexpr int64_t ESZ = CX ? 16 : 8;
+    constexpr int IPR_B = BN / ((!CX && VEC) ? 2 : 1);
+    // a wave-instruction of the B loads spans 64 / IPR_B rows through its 32-bit lane offset
+    if (IPR_B < 64 && (64 / IPR_B) * ldb * ESZ + 4096 >= (int64_t(1) << 32)) return 1;
     FastArgs g;
     g.A = A; g.B = B; g.C = C;
     g.lda = lda; g.ldb = ldb; g.ldc = ldc;
     g.sa = sa; g.sb = sb; g.sc = sc;
-    g.nk = (int)(k / KT);
-    g.tiles_m = (int)(m / BM);
-    g.tiles_n = (int)(n / BN);
+    g.a_end = reinterpret_cast<uint64_t>(A) + (uint64_t)(((batch - 1) * sa + (m - 1) * lda + k) * ESZ);
+    g.b_end = reinterpret_cast<uint64_t>(B) + (uint64_t)(((batch - 1) * sb + (k - 1) * ldb + n) * ESZ);
+    g.m = m; g.n = (int)n; g.k = (int)k;
+    g.nk = (int)cdiv(k, KT);
+    g.tiles_m = (int)cdiv(m, BM);
+    g.tiles_n = (int)cdiv(n, BN);
     g.group_along_m = group_along_m;
     g.accumulate = accumulate ? 1 : 0;
     const int64_t total = (int64_t)g.tiles_m * g.tiles_n * batch;
@@ -398,7 +511,7 @@ static int launch_fast(const double* A, const double* B, double* C, int64_t m, i
     }
     if (P > total) P = total;
     const size_t lds = sizeof(double) * 2 * NP * (BM * (KT + 2) + KT * (CX ? BN + 16 : BN));
-    auto kern = gemm_fast_kernel<CX, TM, TN>;
+    auto kern = gemm_fast_kernel<CX, TM, TN, VEC, EDGE>;
     static bool lds_opt_in = false;
     if (lds > 64 * 1024 && !lds_opt_in) {
         hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -409,36 +522,85 @@ static int launch_fast(const double* A, const double* B, double* C, int64_t m, i
     return launch_status("gemm_fast launch");
 }
 
-// Returns QS_OK after launching, or 1 when the product does not qualify for a
-// fast shape (caller falls back to the general kernel).
+namespace {
+struct FastShape { int id, tm, tn; double weight; };
+// relative full-tile rates of the edge-form shapes (profiles/r01_gemm_notes.txt)
+const FastShape kF64Shapes[] = {{1, 4, 4, 1.00}, {2, 2, 4, 0.93}, {3, 4, 2, 0.93}, {4, 2, 2, 0.85}};
+const FastShape kC128Shapes[] = {{1, 4, 2, 1.00}, {2, 2, 4, 1.00}, {3, 2, 2, 0.95}};
+
+template <size_t N>
+int pick_fast_shape(const FastShape (&cand)[N], int64_t m, int64_t n) {
+    if (g_gemm_fast_shape >= 1 && g_gemm_fast_shape <= (int)N) return g_gemm_fast_shape;
+    int best = cand[0].id;
+    double best_cost = 1e300;
+    for (const FastShape& c : cand) {
+        const double padded = (double)(cdiv(m, 32 * c.tm) * 32 * c.tm) * (double)(cdiv(n, 32 * c.tn) * 32 * c.tn);
+        const double cost = padded / c.weight;
+        if (cost < best_cost) { best_cost = cost; best = c.id; }
+    }
+    return best;
+}
+}  // namespace
+
+// Returns QS_OK after launching, or 1 when the product does not qualify
+// (caller falls back to the general kernel).
 int gemm_fast_try(int dtype, const double* A, const double* B, double* C, int64_t m, int64_t n,
                   int64_t k, int64_t lda, int64_t ldb, int64_t ldc, int64_t batch, int64_t sa,
                   int64_t sb, int64_t sc, int accumulate, int group_along_m, hipStream_t stream) {
     if (!g_gemm_fast) return 1;
     const bool cx = dtype == QS_C128;
     const int64_t esz = cx ? 16 : 8;
-    if (!aligned(A, 16) || !aligned(B, 16) || !aligned(C, cx ? 16 : 8)) return 1;
-    if (!cx && ((lda & 1) || (ldb & 1) || (sa & 1) || (sb & 1))) return 1;   // 16-byte loads
-    if (!cx && (!aligned(C, 16) || (ldc & 1) || (sc & 1))) return 1;          // 16-byte stores
-    // the lane offset of the A loads is 32-bit: 32 rows of lda elements must fit
+    if (cx && (!aligned(A, 16) || !aligned(B, 16) || !aligned(C, 16))) return 1;
+    // the lane offsets of the loads are 32-bit: one item step of rows must fit
     if (32 * lda * esz + 256 >= (int64_t(1) << 32)) return 1;
-#define QS_FAST(CXF, TMF, TNF)                                                                      \
-    if (m % (32 * TMF) == 0 && n % (32 * TNF) == 0)                                                  \
-        return launch_fast<CXF, TMF, TNF>(A, B, C, m, n, k, lda, ldb, ldc, batch, sa, sb, sc,        \
-                                          accumulate, group_along_m, stream);
-    if (!cx) {
-        if (k % 16) return 1;
-        QS_FAST(false, 4, 4)     // 128 x 128
-        QS_FAST(false, 2, 4)     //  64 x 128
-    } else {
-        if (k % 8) return 1;
-        if (m >= n) { QS_FAST(true, 4, 2) }   // 128 x 64
-        QS_FAST(true, 2, 4)      //  64 x 128
-        QS_FAST(true, 4, 2)      // 128 x  64
-        QS_FAST(true, 2, 2)      //  64 x  64
+    if (m >= (int64_t(1) << 31) - 256 || n >= (int64_t(1) << 31) - 256 || k >= (int64_t(1) << 31) - 256) return 1;
+    // 16-byte accesses: aligned bases, even strides (complex elements are 16 bytes by themselves)
+    const bool vec = cx || (aligned(A, 16) && aligned(B, 16) && aligned(C, 16) && !(lda & 1) && !(ldb & 1) &&
+                            !(ldc & 1) && !(sa & 1) && !(sb & 1) && !(sc & 1) && !(n & 1));
+#define QS_FAST(CXF, TMF, TNF, VECF, EDGEF)                                                          \
+    return launch_fast<CXF, TMF, TNF, VECF, EDGEF>(A, B, C, m, n, k, lda, ldb, ldc, batch, sa, sb, sc, \
+                                                    accumulate, group_along_m, stream)
+    // ---- exact form: every extent a whole number of tiles
+    if (!cx && vec && k % 16 == 0) {
+        if (m % 128 == 0 && n % 128 == 0) QS_FAST(false, 4, 4, true, false);
+        if (m % 64 == 0 && n % 128 == 0) QS_FAST(false, 2, 4, true, false);
+    }
+    if (cx && k % 8 == 0) {
+        if (m >= n && m % 128 == 0 && n % 64 == 0) QS_FAST(true, 4, 2, true, false);
+        if (m % 64 == 0 && n % 128 == 0) QS_FAST(true, 2, 4, true, false);
+        if (m % 128 == 0 && n % 64 == 0) QS_FAST(true, 4, 2, true, false);
+        if (m % 64 == 0 && n % 64 == 0) QS_FAST(true, 2, 2, true, false);
+    }
+    // ---- edge form.  Measured on MI355X against the general kernel (profiles/r01_gemm_notes.txt):
+    // +3...9 % for fp64 products whose m and n are both >= 100 (l = 100, 160, 192, 200), slower
+    // below that (short tile lists: the general kernel's small and 96-wide shapes win) and for
+    // complex128 (whose general kernel is already light on VALU work per MFMA).
+    // g_gemm_fast: 1 = that policy, 3 = edge form wherever it applies (tests, tuning).
+    if (g_gemm_fast != 1 && g_gemm_fast != 3) return 1;
+    if (g_gemm_fast == 1 && (cx || m < 100 || n < 100)) return 1;
+    if (cx) {
+        switch (pick_fast_shape(kC128Shapes, m, n)) {
+            case 1: QS_FAST(true, 4, 2, true, true);
+            case 2: QS_FAST(true, 2, 4, true, true);
+            default: QS_FAST(true, 2, 2, true, true);
+        }
+    }
+    const int shape = pick_fast_shape(kF64Shapes, m, n);
+    if (vec) {
+        switch (shape) {
+            case 1: QS_FAST(false, 4, 4, true, true);
+            case 2: QS_FAST(false, 2, 4, true, true);
+            case 3: QS_FAST(false, 4, 2, true, true);
+            default: QS_FAST(false, 2, 2, true, true);
+        }
+    }
+    switch (shape) {
+        case 1: QS_FAST(false, 4, 4, false, true);
+        case 2: QS_FAST(false, 2, 4, false, true);
+        case 3: QS_FAST(false, 4, 2, false, true);
+        default: QS_FAST(false, 2, 2, false, true);
     }
 #undef QS_FAST
-    return 1;
 }
 
 }  // namespace qs

@@ -356,6 +356,83 @@ def test_fast_and_general_kernels_agree_l128(K, dt):
     assert abs(lhs - rhs).item() <= 1e-10 * abs(rhs).item()
 
 
+# ------------------------------------------- edge form of the fast kernel (any extent)
+
+
+@pytest.mark.parametrize("cplx", [False, True])
+@pytest.mark.parametrize("m,n,k,batch", [(1, 1, 1, 1), (55, 55, 55, 3), (166, 55, 55, 1), (100, 100, 100, 2),
+                                          (130, 258, 17, 1), (200, 136, 40, 2), (129, 65, 33, 1),
+                                          (64, 300, 15, 1), (257, 102, 96, 1)])
+def test_edge_form_product_vs_oracle(K, m, n, k, batch, cplx):
+    # gemm_fast = 3 routes every product through the VALU-free kernel's edge form: odd extents
+    # take its 8-byte accesses, even ones the 16-byte ones; K tails are zeroed in registers
+    rng = np.random.default_rng(m * 7 + n * 3 + k + batch + cplx)
+    A = rng.standard_normal((m, k))
+    B = rng.standard_normal((batch, k, n))
+    if cplx:
+        A = A + 1j * rng.standard_normal((m, k))
+        B = B + 1j * rng.standard_normal((batch, k, n))
+    ref = np.matmul(A, B)
+    try:
+        K.tuning_set("gemm_fast", 0)
+        general = host(K.matmul(dev(A), dev(B)))
+        for shape in (0, 1, 2, 3, 4):
+            K.tuning_set("gemm_fast", 3)
+            K.tuning_set("gemm_fast_shape", shape)
+            got = host(K.matmul(dev(A), dev(B)))
+            assert relerr(got, ref) <= 1e-13, f"shape={shape}"
+            # same k order as the general kernel: identical bits
+            assert np.array_equal(got, general), f"shape={shape}"
+            out = dev(ref.copy())
+            K.matmul(dev(A), dev(B), out=out, accumulate=True)
+            assert relerr(host(out), 2 * ref) <= 1e-13, f"shape={shape} accumulate"
+    finally:
+        K.tuning_set("gemm_fast", 1)
+        K.tuning_set("gemm_fast_shape", 0)
+
+
+def test_edge_form_keeps_non_finite_values_in_their_rows(K):
+    # the K tail is removed with selects, not by multiplying with zero: a NaN/Inf in one row of A
+    # (or one column of B) must not reach any other row (column) of the product
+    rng = np.random.default_rng(77)
+    m, n, k = 70, 58, 21          # lda == k: the tail of row i is the head of row i + 1
+    A = rng.standard_normal((m, k))
+    B = rng.standard_normal((k, n))
+    A[31, 0] = np.nan
+    A[40, 3] = np.inf
+    B[2, 57] = np.nan
+    with np.errstate(invalid="ignore"):
+        ref = A @ B
+    try:
+        K.tuning_set("gemm_fast", 3)
+        got = host(K.matmul(dev(A), dev(B)))
+    finally:
+        K.tuning_set("gemm_fast", 1)
+    assert np.array_equal(np.isnan(got), np.isnan(ref))
+    ok = np.isfinite(ref)
+    np.testing.assert_allclose(got[ok], ref[ok], rtol=1e-12, atol=1e-12)
+
+
+@pytest.mark.parametrize("dt,l", [(torch.float64, 55), (torch.float64, 100), (torch.complex128, 36)])
+def test_edge_form_transform_equals_general_kernel(K, dt, l):
+    g = torch.Generator(device="cuda:0").manual_seed(l)
+    u = torch.rand(l, l, l, l, dtype=torch.float64, device="cuda:0", generator=g).to(dt)
+    C = torch.randn(l, l, dtype=torch.float64, device="cuda:0", generator=g).to(dt) / l**0.5
+    Ct = C.conj().T.contiguous()
+    try:
+        K.tuning_set("gemm_fast", 0)
+        gen = K.transform_two_body(u, C, Ct)
+        K.tuning_set("gemm_fast", 3)
+        edge = K.transform_two_body(u, C, Ct)
+    finally:
+        K.tuning_set("gemm_fast", 1)
+    assert torch.equal(edge, gen)
+    x, y, z, w = (torch.randn(l, dtype=torch.float64, device="cuda:0", generator=g).to(dt) for _ in range(4))
+    lhs = torch.einsum("pqrs,p,q,r,s->", edge, x, y, z, w)
+    rhs = torch.einsum("abcd,a,b,c,d->", u, Ct.T @ x, Ct.T @ y, C @ z, C @ w)
+    assert abs(lhs - rhs).item() <= 1e-10 * abs(rhs).item()
+
+
 # ------------------------------------------- short-and-wide streaming product (qs_gemm_skinny.hip)
 
 
