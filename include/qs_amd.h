@@ -186,7 +186,9 @@ int qs_tdho_coulomb_elements(void* out, int64_t l, int64_t p_lo, int64_t p_hi,
  *     shape 1..4, 0 = automatic), "gemm_fast_persist"
  *     (0 one workgroup per tile, 1 automatic, 2 always persistent, >= 3 tiles
  *     per workgroup),
- *     "gemm_skinny" (0 = never use the streaming short-and-wide kernel).
+ *     "gemm_skinny" (0 = never use the streaming short-and-wide kernel),
+ *     "gemm_stream" (0 = never use the small-coefficient streaming kernel,
+ *     2 = never split the rows of A over two waves).
  *   qs_probe_mfma_f64: register-resident fp64 MFMA loop, `blocks` workgroups
  *     of 4 waves, each wave issuing iters*8 v_mfma_f64_16x16x4_f64
  *     (flops = blocks*4*iters*8*2048); `sink` is a device scratch of

@@ -85,6 +85,7 @@ int qs_tuning_set(const char* key, int64_t value) {
     if (!strcmp(key, "gemm_pipe")) { g_gemm_pipe = (int)value; return QS_OK; }
     if (!strcmp(key, "gemm_fast")) { g_gemm_fast = (int)value; return QS_OK; }
     if (!strcmp(key, "gemm_skinny")) { g_gemm_skinny = (int)value; return QS_OK; }
+    if (!strcmp(key, "gemm_stream")) { g_gemm_stream = (int)value; return QS_OK; }
     if (!strcmp(key, "gemm_fast_persist")) { g_gemm_fast_persist = (int)value; return QS_OK; }
     if (!strcmp(key, "gemm_fast_shape")) { g_gemm_fast_shape = (int)value; return QS_OK; }
     return QS_ERR_BAD_EXTENT;

@@ -47,6 +47,11 @@ int gemm_fast_try(int dtype, const double* A, const double* B, double* C, int64_
                   int64_t k, int64_t lda, int64_t ldb, int64_t ldc, int64_t batch, int64_t sa,
                   int64_t sb, int64_t sc, int accumulate, int group_along_m, hipStream_t stream);
 
+// Small-coefficient streaming product, m, k <= 64 (qs_gemm_stream.hip): same return convention.
+int gemm_stream_try(int dtype, const double* A, const double* B, double* C, int64_t m, int64_t n,
+                    int64_t k, int64_t lda, int64_t ldb, int64_t ldc, int64_t batch, int64_t sa,
+                    int64_t sb, int64_t sc, int accumulate, hipStream_t stream);
+
 // Short-and-wide streaming product (qs_gemm_skinny.hip): same return convention.
 int gemm_skinny_try(int dtype, const double* A, const double* B, double* C, int64_t m, int64_t n,
                     int64_t k, int64_t lda, int64_t ldb, int64_t ldc, int64_t batch, int accumulate,
@@ -74,5 +79,6 @@ extern int g_gemm_fast;
 extern int g_gemm_fast_persist;
 extern int g_gemm_fast_shape;
 extern int g_gemm_skinny;
+extern int g_gemm_stream;
 
 }  // namespace qs

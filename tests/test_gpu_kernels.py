@@ -455,6 +455,45 @@ def test_skinny_product_vs_oracle(K, m, k, cplx):
     K.tuning_set("gemm_skinny", 1)
 
 
+# ------------------------------------------- small-coefficient streaming product (qs_gemm_stream.hip)
+
+
+@pytest.mark.parametrize("m,k,n,batch", [(55, 55, 55 * 55, 55), (55, 55, 55, 3025), (64, 64, 4096, 16),
+                                          (1, 1, 70000, 1), (17, 3, 1000, 70), (40, 61, 33, 2100),
+                                          (64, 5, 100001, 1), (33, 64, 130, 600)])
+def test_stream_product_vs_oracle(K, m, k, n, batch):
+    # the c, b, a contractions of a small-l transform: A (m x k) is Ct or C^T, shared by the batch
+    rng = np.random.default_rng(m * 1000 + k * 10 + batch)
+    A = rng.standard_normal((m, k))
+    B = rng.standard_normal((batch, k, n))
+    ref = np.matmul(A, B)
+    try:
+        K.tuning_set("gemm_stream", 0)
+        general = host(K.matmul(dev(A), dev(B)))
+        for knob in (1, 2):       # 2 = never split the rows of A over two waves
+            K.tuning_set("gemm_stream", knob)
+            got = host(K.matmul(dev(A), dev(B)))
+            assert relerr(got, ref) <= 1e-13, f"gemm_stream={knob}"
+            assert np.array_equal(got, general), f"gemm_stream={knob}: same k order as the tiled kernels"
+    finally:
+        K.tuning_set("gemm_stream", 1)
+
+
+def test_stream_product_keeps_non_finite_values_in_their_columns(K):
+    rng = np.random.default_rng(5)
+    m, k, n = 30, 23, 70001            # k tail of 3, odd n: 8-byte accesses, clamped last block
+    A = rng.standard_normal((m, k))
+    B = rng.standard_normal((k, n))
+    B[22, 70000] = np.nan
+    B[0, 17] = np.inf
+    with np.errstate(invalid="ignore"):
+        ref = A @ B
+    got = host(K.matmul(dev(A), dev(B)))
+    assert np.array_equal(np.isnan(got), np.isnan(ref))
+    ok = np.isfinite(ref)
+    np.testing.assert_allclose(got[ok], ref[ok], rtol=1e-12, atol=1e-12)
+
+
 def test_replicated_layout_matches_full_transform(K):
     # sharded.transform_two_body_replicated on one GPU, every rank's slab (uses the skinny product)
     from quantum_systems_amd import sharded

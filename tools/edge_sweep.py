@@ -32,9 +32,13 @@ def run(l, dt):
     kf = 4 if dt.is_complex else 1
     res = []
     ref = None
-    for label, fast, shape in [("general", 2, 0), ("edge auto", 1, 0)] + [(f"edge s{s}", 1, s) for s in (1, 2, 3, 4)]:
+    variants = [("general", 2, 0), ("edge auto", 3, 0)] + [(f"edge s{s}", 3, s) for s in (1, 2, 3, 4)]
+    if os.environ.get("QS_SWEEP") == "stream":
+        variants = [("tiled", 1, 0, 0), ("stream", 1, 0, 1), ("stream no-split", 1, 0, 2)]
+    for label, fast, shape, *rest in variants:
         if dt.is_complex and shape == 4:
             continue
+        K.tuning_set("gemm_stream", rest[0] if rest else 0)
         K.tuning_set("gemm_fast", fast)
         K.tuning_set("gemm_fast_shape", shape)
         reps = 20 if l <= 64 else 5
@@ -47,6 +51,7 @@ def run(l, dt):
         res.append(f"{label} {kf*8*l**5/t/1e12:6.2f} ({err:.0e})")
     K.tuning_set("gemm_fast", 1)
     K.tuning_set("gemm_fast_shape", 0)
+    K.tuning_set("gemm_stream", 1)
     print(f"l={l:4d} {str(dt)[6:]:>10}: " + " | ".join(res), flush=True)
     del u, out, ref
     K.workspace.release()
