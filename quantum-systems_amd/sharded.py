@@ -264,3 +264,86 @@ def transform_two_body_sharded_inplace(u_bslab, C, C_tilde=None, rank=0, world=1
     for g in range(world):
         engine.matmul(Ct[:, g * bl:(g + 1) * bl].contiguous(), xv[g], out=out, accumulate=g > 0)
     return out.reshape(pc, L, L, L)
+
+
+# ---------------------------------------------------------------------------
+# First consumers of a p-sharded u: Fock matrix and reference energy
+# (SURVEY 8f #2).  Every term needs u[p, ...] for ONE leading index p, so each
+# rank works on its slab and the node exchanges l*l (Fock rows) or one number
+# (energy) -- u stays sharded end to end.
+# ---------------------------------------------------------------------------
+
+
+def fock_rows(h, u_slab, n_occ, p_lo, spin_orbitals=False):
+    """Rows ``p_lo : p_lo + u_slab.shape[0]`` of the Fock matrix.
+
+    spatial orbitals (closed shell, spatial_orbital_system.py:152-190):
+        f_pq = h_pq + 2 u_piqi - u_piiq
+    spin orbitals with anti-symmetrised u (general_orbital_system.py:123-159):
+        f_pq = h_pq + u_piqi
+    summed over the ``n_occ`` occupied orbitals i.  ``u_slab = u[p_lo:p_hi]``.
+    """
+    pc = u_slab.shape[0]
+    f = h[p_lo:p_lo + pc].clone()
+    o = slice(0, n_occ)
+    direct = torch.einsum("piqi->pq", u_slab[:, o, :, o])
+    if spin_orbitals:
+        return f + direct
+    return f + 2 * direct - torch.einsum("piiq->pq", u_slab[:, o, o, :])
+
+
+def construct_fock_matrix_sharded(h, u_slab, n_occ, rank=0, world=1, spin_orbitals=False, group=None):
+    """Full Fock matrix on every rank from a p-sharded ``u``: slab-local rows,
+    then one all-gather of l*l numbers."""
+    l = h.shape[0]
+    part = SlabPartition(l, world)
+    lo, hi = part.bounds(rank)
+    if tuple(u_slab.shape[:1]) != (hi - lo,):
+        raise ValueError(f"rank {rank}: slab has {u_slab.shape[0]} rows, expected {hi - lo}")
+    rows = fock_rows(h, u_slab, n_occ, lo, spin_orbitals)
+    if world == 1:
+        return rows
+    width = 2 if rows.is_complex() else 1
+    biggest = max(part.count(r) for r in range(world)) * l * width
+    send = torch.zeros(biggest, dtype=torch.float64, device=rows.device)
+    flat = _as_real_flat(rows)
+    send[: flat.numel()] = flat
+    recv = torch.empty(world * biggest, dtype=torch.float64, device=rows.device)
+    dist.all_gather_into_tensor(recv, send, group=group)
+    f = torch.empty((l, l), dtype=rows.dtype, device=rows.device)
+    ff = _as_real_flat(f)
+    for r in range(world):
+        r_lo, r_hi = part.bounds(r)
+        n = (r_hi - r_lo) * l * width
+        ff[r_lo * l * width: r_lo * l * width + n] = recv[r * biggest: r * biggest + n]
+    return f
+
+
+def reference_energy_sharded(h, u_slab, n_occ, rank=0, world=1, spin_orbitals=False,
+                             nuclear_repulsion_energy=0.0, group=None):
+    """Reference-determinant energy from a p-sharded ``u``.
+
+    spatial (spatial_orbital_system.py:106-150): 2 h_ii + 2 u_ijij - u_ijji + E_nuc
+    spin orbitals (general_orbital_system.py:75-121): h_ii + 1/2 u_ijij + E_nuc
+    The leading index i of ``u`` is the sharded one: each rank sums its occupied
+    rows, one all-reduce of a single number closes the sum.
+    """
+    l = h.shape[0]
+    lo, hi = SlabPartition(l, world).bounds(rank)
+    i_lo, i_hi = min(lo, n_occ), min(hi, n_occ)          # occupied rows of this slab
+    o = slice(0, n_occ)
+    part = torch.zeros((), dtype=u_slab.dtype, device=u_slab.device)
+    if i_hi > i_lo:
+        blk = u_slab[i_lo - lo:i_hi - lo, o, :, :][:, :, i_lo:i_hi, o]    # u[i, j, i', j'], i' in the same rows
+        coul = torch.einsum("ijij->", blk)
+        hd = torch.diagonal(h)[i_lo:i_hi].sum().to(u_slab.dtype)
+        if spin_orbitals:
+            part = hd + 0.5 * coul
+        else:
+            part = 2 * hd + 2 * coul - torch.einsum("ijji->", u_slab[i_lo - lo:i_hi - lo, o, o, :][:, :, :, i_lo:i_hi])
+    if world > 1:
+        buf = torch.view_as_real(part.to(torch.complex128).reshape(1)).reshape(-1).contiguous()
+        dist.all_reduce(buf, group=group)
+        total = torch.view_as_complex(buf.reshape(1, 2))[0]
+        part = total if u_slab.is_complex() else total.real
+    return part + nuclear_repulsion_energy

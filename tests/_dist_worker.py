@@ -102,6 +102,27 @@ def main():
         np.testing.assert_allclose(
             slab3.numpy(), orc.transform_two_body(u, C)[p_lo:p_hi], rtol=1e-12, atol=1e-12
         )
+    # first consumers of a p-sharded u: Fock matrix and reference energy,
+    # against the formulas of spatial_orbital_system.py:106-190 / general_orbital_system.py:75-159
+    for (l, n_occ, cplx) in [(7, 3, False), (6, 6, True), (5, 1, True)]:
+        h = rng.standard_normal((l, l))
+        u = rng.standard_normal((l,) * 4)
+        if cplx:
+            h = h + 1j * rng.standard_normal((l, l))
+            u = u + 1j * rng.standard_normal((l,) * 4)
+        o = slice(0, n_occ)
+        lo, hi = sharded.SlabPartition(l, world).bounds(rank)
+        th, tslab = torch.from_numpy(h), torch.from_numpy(np.ascontiguousarray(u[lo:hi]))
+        f_s = h + 2 * np.einsum("piqi->pq", u[:, o, :, o]) - np.einsum("piiq->pq", u[:, o, o, :])
+        f_g = h + np.einsum("piqi->pq", u[:, o, :, o])
+        e_s = 2 * np.trace(h[o, o]) + 2 * np.einsum("ijij->", u[o, o, o, o]) - np.einsum("ijji->", u[o, o, o, o]) + 0.25
+        e_g = np.trace(h[o, o]) + 0.5 * np.einsum("ijij->", u[o, o, o, o]) + 0.25
+        for spin, f_ref, e_ref in ((False, f_s, e_s), (True, f_g, e_g)):
+            f = sharded.construct_fock_matrix_sharded(th, tslab, n_occ, rank, world, spin_orbitals=spin)
+            np.testing.assert_allclose(f.numpy(), f_ref, rtol=1e-12, atol=1e-12)
+            e = sharded.reference_energy_sharded(th, tslab, n_occ, rank, world, spin_orbitals=spin,
+                                                 nuclear_repulsion_energy=0.25)
+            np.testing.assert_allclose(complex(e), e_ref, rtol=1e-12, atol=1e-12)
     dist.barrier()
     dist.destroy_process_group()
     print(f"rank {rank}/{world} ok")
