@@ -331,3 +331,45 @@ def transform_flops(L, M, complex_=False):
     """2(L^4 M + L^3 M^2 + L^2 M^3 + L M^4) real flops, x4 for complex128."""
     k = 4 if complex_ else 1
     return k * 2 * (L**4 * M + L**3 * M**2 + L**2 * M**3 + L * M**4)
+
+
+# --------------------------------------------------------------------------
+# grid / DVR contractions of the same family (SURVEY 8f #4)
+# --------------------------------------------------------------------------
+
+
+def two_body_from_grid(K, C, C_tilde=None, antisymmetrize=False):
+    """out[p,q,r,s] = sum_ab Ct[p,a] Ct[q,b] K[a,b] C[a,r] C[b,s]
+    (sinc_dvr/one_dim/sinc_dvr.py:227-256: transform of a 2-d ``u``; the fused
+    anti-symmetrisation subtracts the r <-> s exchanged contraction).  With
+    ``C_tilde = C.T`` this is the quadrature of one_dim_qd.py:275-280."""
+    if C_tilde is None:
+        C_tilde = C.conj().T
+    out = np.einsum("bs,ar,qb,pa,ab->pqrs", C, C, C_tilde, C_tilde, K, optimize=True)
+    if antisymmetrize:
+        out = out - np.einsum("br,as,qb,pa,ab->pqrs", C, C, C_tilde, C_tilde, K, optimize=True)
+    return out
+
+
+def odqd_setup(l, grid_length, num_grid_points, potential, a=0.25, alpha=1.0, beta=0.0):
+    """Arrays of the 1-D quantum dot basis (one_dim_qd.py:232-289): the lowest
+    ``l`` eigenpairs of the three-point finite-difference Hamiltonian on the
+    interior grid points, the grid functions, and the quadratures for ``u`` and
+    ``position``.  ``potential`` is a callable V(x).  Returns a dict."""
+    import scipy.linalg
+
+    grid = np.linspace(-grid_length, grid_length, num_grid_points)
+    x = grid[1:-1]
+    dx = grid[1] - grid[0]
+    eps, C = scipy.linalg.eigh_tridiagonal(
+        1.0 / dx**2 + potential(x), -np.ones(num_grid_points - 3) / (2 * dx**2),
+        select="i", select_range=(0, l - 1),
+    )
+    spf = np.zeros((l, num_grid_points), dtype=np.complex128)
+    spf[:, 1:-1] = C.T / np.sqrt(dx)
+    K = alpha / np.sqrt((x[None, :] - x[:, None]) ** 2 + a**2)
+    u = np.einsum("pa,qb,pc,qd,pq->abcd", C, C, C, C, K, optimize=True)
+    position = np.zeros((1, l, l), dtype=np.complex128)
+    position[0] = np.einsum("pa,p,pb->ab", C, x + beta * x**2, C, optimize=True)
+    return {"grid": grid, "eigen_energies": eps, "C": C, "spf": spf,
+            "h": np.diag(eps).astype(np.complex128), "s": np.eye(l), "u": u, "position": position}

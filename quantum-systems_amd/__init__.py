@@ -16,6 +16,7 @@ from .array_module import DeviceArray, DeviceModule, hip
 from .basis_set import BasisSet
 from .custom_system import construct_custom_system, setup_basis_set
 from .general_orbital_system import GeneralOrbitalSystem
+from .one_dim_qd import ODQD
 from .random_basis import RandomBasisSet
 from .spatial_orbital_system import SpatialOrbitalSystem
 from .system import QuantumSystem
@@ -24,6 +25,6 @@ from .two_dim_ho import TwoDimensionalHarmonicOscillator
 __all__ = [
     "BasisSet", "RandomBasisSet", "QuantumSystem", "SpatialOrbitalSystem",
     "GeneralOrbitalSystem", "setup_basis_set", "construct_custom_system",
-    "TwoDimensionalHarmonicOscillator",
+    "TwoDimensionalHarmonicOscillator", "ODQD",
     "hip", "DeviceModule", "DeviceArray", "kernels", "sharded",
 ]

@@ -314,5 +314,38 @@ def spin_squared_two_body(S, antisymmetrize=False, p_lo=0, p_hi=None):
     return out
 
 
+def two_body_from_grid(K, C, C_tilde=None, antisymmetrize=False):
+    """Two-body elements of an interaction that is DIAGONAL on a grid / DVR basis,
+
+        out[p,q,r,s] = sum_ab Ct[p,a] Ct[q,b] K[a,b] C[a,r] C[b,s]
+
+    -- the transform of a sinc-DVR ``u`` kept in its 2-d form
+    (sinc_dvr/one_dim/sinc_dvr.py:217-246, optional fused anti-symmetrisation
+    :247-256) and, with ``C_tilde = C.T``, the grid quadrature that builds the
+    ``u`` of a 1-D quantum dot (quantum_dots/one_dim/one_dim_qd.py:275-280).
+    Two GEMMs on the MFMA kernels instead of a five-operand einsum:
+    ``rho[a,(p,r)] = Ct[p,a] C[a,r]``, ``W = K rho``, ``out[(p,r),(q,s)] = rho^T W``;
+    O(N^2 M^2 + N M^4) for N grid points and M orbitals.  ``C_tilde`` defaults to
+    ``C.conj().T`` as in the reference."""
+    Ct = default_bra(C) if C_tilde is None else C_tilde
+    dt = result_dtype(K, C, Ct)
+    K, C, Ct = _dev(K, dt), _dev(C, dt), _dev(Ct, dt)
+    N, M = C.shape
+    if tuple(K.shape) != (N, N) or tuple(Ct.shape) != (M, N):
+        raise ValueError(f"K {tuple(K.shape)}, C {tuple(C.shape)}, C_tilde {tuple(Ct.shape)} do not fit")
+    rho = (Ct.transpose(0, 1).unsqueeze(2) * C.unsqueeze(1)).reshape(N, M * M)
+    W = matmul(K, rho)                                            # (N, (q,s))
+    out = matmul(rho.transpose(0, 1).contiguous(), W)             # ((p,r), (q,s))
+    out = out.reshape(M, M, M, M).permute(0, 2, 1, 3).contiguous()
+    if antisymmetrize:
+        antisymmetrize_(out)
+    return out
+
+
+def antisymmetrize_(u):
+    """In-place form of ``antisymmetrize``."""
+    return antisymmetrize(u, out=u)
+
+
 def tuning_set(key, value):
     check(_lib.load().qs_tuning_set(key.encode(), int(value)), "qs_tuning_set")

@@ -320,9 +320,60 @@ def case_tdho_coulomb():
          one_body_l55=np.diag(get_one_body_elements(55)))
 
 
+def case_odqd():
+    """1-D quantum dot.  (i) the reference class itself on small grids, all
+    fields; (ii) the reference's own regression files tests/dat/od*_{h,u,spf,dipole_moment}.npy
+    (GeneralOrbitalSystem(2, ODQD(10, ..., 1001, potential)), 20 spin orbitals): h and the dipole
+    in full, u and spf as a seeded sample of entries plus their absolute sums (the files are
+    2.5 MB each; the reference compares them by absolute value, tests/test_one_dim_qd.py:127-142);
+    (iii) the 2-d-u transform of ODSincDVR on a small case."""
+    ODQD = qs.ODQD
+    for tag, pot, args in (
+        ("ho", ODQD.HOPotential(1.0), dict(l=6, grid_length=5, num_grid_points=101)),
+        ("dw", ODQD.DWPotential(1.0, 5.0), dict(l=5, grid_length=6, num_grid_points=152, a=0.3, alpha=0.9, beta=0.1)),
+    ):
+        bs = ODQD(potential=pot, **args)
+        save(f"odqd_small_{tag}", grid=bs.grid, eigen_energies=bs.eigen_energies, spf=bs.spf, h=bs.h,
+             s=bs.s, u=bs.u, position=bs.position,
+             params=np.array([args["l"], args["grid_length"], args["num_grid_points"],
+                              args.get("a", 0.25), args.get("alpha", 1.0), args.get("beta", 0.0)]))
+    rng = np.random.default_rng(7)
+    dat = "/root/reference/tests/dat"
+    out = {}
+    for name in ("odho", "oddw", "odgauss", "oddw_smooth"):
+        h = np.load(os.path.join(dat, f"{name}_h.npy"))
+        dip = np.load(os.path.join(dat, f"{name}_dipole_moment.npy"))
+        u = np.load(os.path.join(dat, f"{name}_u.npy"))
+        spf = np.load(os.path.join(dat, f"{name}_spf.npy"))
+        ui = rng.integers(0, u.shape[0], size=(3000, 4))
+        si = np.stack([rng.integers(0, spf.shape[0], 2000), rng.integers(0, spf.shape[1], 2000)], axis=1)
+        out.update({
+            f"{name}_h": h, f"{name}_dipole_moment": dip,
+            f"{name}_u_idx": ui, f"{name}_u_val": u[tuple(ui.T)], f"{name}_u_abs_sum": np.abs(u).sum(),
+            f"{name}_u_shape": np.array(u.shape),
+            f"{name}_spf_idx": si, f"{name}_spf_val": spf[tuple(si.T)], f"{name}_spf_abs_sum": np.abs(spf).sum(),
+            f"{name}_spf_shape": np.array(spf.shape),
+        })
+    save("odqd_reference_regression_files", **out)
+    # sinc-DVR: 2-d u transformed with a complex C, with and without the fused anti-symmetrisation
+    from quantum_systems.sinc_dvr.one_dim.sinc_dvr import ODSincDVR
+
+    dvr = ODSincDVR(12, 6.0, potential=ODSincDVR.HOPotential(0.5))
+    C = crand(rng, 12, 7)
+    Ct = crand(rng, 7, 12)
+    save("sinc_dvr_small", h=dvr.h, s=dvr.s, spf=dvr.spf, u2d=dvr.u, position=dvr.position, grid=dvr.grid,
+         C=C, C_tilde=Ct,
+         u_default_bra=dvr.transform_two_body_elements(dvr.u, C, np),
+         u_ctilde=dvr.transform_two_body_elements(dvr.u, C, np, C_tilde=Ct),
+         u_ctilde_as=dvr.transform_two_body_elements(dvr.u, C, np, anti_symmetrize=True, C_tilde=Ct))
+
+
 if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "tdho":
         case_tdho_coulomb()
+        sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "odqd":
+        case_odqd()
         sys.exit(0)
     case_transforms()
     case_spin_statics()
@@ -331,3 +382,4 @@ if __name__ == "__main__":
     case_gos_small()
     case_change_basis_with_spf()
     case_tdho_coulomb()
+    case_odqd()

@@ -1,0 +1,110 @@
+"""1-D quantum dot (ODQD) and the grid / DVR contraction on the GPU: the product
+classes against golden vectors made by the reference's ODQD / ODSincDVR and against the
+reference's regression files (tests/test_one_dim_qd.py:127-142 restated)."""
+
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import qs_oracle as orc
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def H(x):
+    from quantum_systems_amd.array_module import to_host
+
+    return np.asarray(to_host(x))
+
+
+@pytest.mark.parametrize("use_device_module", [False, True])
+@pytest.mark.parametrize("tag", ["ho", "dw"])
+def test_odqd_matches_reference_class(tag, use_device_module):
+    import quantum_systems_amd as qsa
+
+    g = np.load(os.path.join(GOLD, f"odqd_small_{tag}.npz"))
+    l, length, n, a, alpha, beta = g["params"]
+    pot = qsa.ODQD.HOPotential(1.0) if tag == "ho" else qsa.ODQD.DWPotential(1.0, 5.0)
+    kw = dict(np=qsa.hip) if use_device_module else {}
+    bs = qsa.ODQD(int(l), length, int(n), a=a, alpha=alpha, beta=beta, potential=pot, **kw)
+    assert bs.l == int(l) and bs.dim == 1
+    np.testing.assert_allclose(bs.eigen_energies, g["eigen_energies"], rtol=1e-12)
+    np.testing.assert_allclose(H(bs.h), g["h"], atol=1e-12)
+    np.testing.assert_allclose(H(bs.s), g["s"], atol=0)
+    np.testing.assert_allclose(np.abs(H(bs.spf)), np.abs(g["spf"]), atol=1e-10)
+    np.testing.assert_allclose(np.abs(H(bs.position)), np.abs(g["position"]), atol=1e-10)
+    u = H(bs.u)
+    assert u.dtype == np.float64 and H(bs.h).dtype == np.complex128
+    np.testing.assert_allclose(np.abs(u), np.abs(g["u"]), atol=1e-10)
+    # same eigenvector signs as the oracle on this host: element-wise, no absolute values
+    st = orc.odqd_setup(int(l), length, int(n), pot, a=a, alpha=alpha, beta=beta)
+    np.testing.assert_allclose(u, st["u"], rtol=1e-11, atol=1e-13)
+    # symmetries of a real local interaction
+    np.testing.assert_allclose(u, u.transpose(1, 0, 3, 2), atol=1e-12)
+    np.testing.assert_allclose(u, u.transpose(2, 1, 0, 3), atol=1e-12)
+
+
+REGRESSION = {
+    "odho": (5, lambda q: q.ODQD.HOPotential(1)),
+    "oddw": (6, lambda q: q.ODQD.DWPotential(1, 5)),
+    "odgauss": (20, lambda q: q.ODQD.GaussianPotential(1, 0, 2.5, np=np)),
+    "oddw_smooth": (5, lambda q: q.ODQD.DWPotentialSmooth(a=5)),
+}
+
+
+@pytest.mark.parametrize("name", list(REGRESSION))
+def test_odqd_systems_like_reference(name):
+    # tests/test_one_dim_qd.py:127-142 on sampled entries of the reference's own files
+    import quantum_systems_amd as qsa
+
+    g = np.load(os.path.join(GOLD, "odqd_reference_regression_files.npz"))
+    length, make = REGRESSION[name]
+    odqd = qsa.GeneralOrbitalSystem(2, qsa.ODQD(10, length, 1001, potential=make(qsa)))
+    assert odqd.l == 20
+    np.testing.assert_allclose(np.abs(g[f"{name}_dipole_moment"]), np.abs(H(odqd.position)), atol=1e-9)
+    np.testing.assert_allclose(g[f"{name}_h"], H(odqd.h), atol=1e-10)
+    u = H(odqd.u)
+    ui = g[f"{name}_u_idx"]
+    np.testing.assert_allclose(np.abs(g[f"{name}_u_val"]), np.abs(u[tuple(ui.T)]), atol=1e-10)
+    np.testing.assert_allclose(g[f"{name}_u_abs_sum"], np.abs(u).sum(), rtol=1e-9)
+    spf = H(odqd.spf)
+    si = g[f"{name}_spf_idx"]
+    np.testing.assert_allclose(np.abs(g[f"{name}_spf_val"]), np.abs(spf[tuple(si.T)]), atol=1e-10)
+    # anti-symmetry of the spin-orbital elements (tests/test_one_dim_qd.py:145-172)
+    np.testing.assert_allclose(u, -u.transpose(0, 1, 3, 2), atol=1e-8)
+    np.testing.assert_allclose(u, -u.transpose(1, 0, 2, 3), atol=1e-8)
+    np.testing.assert_allclose(u, u.transpose(1, 0, 3, 2), atol=1e-8)
+
+
+def test_two_body_from_grid_matches_sinc_dvr_transform():
+    from quantum_systems_amd import kernels as K
+
+    g = np.load(os.path.join(GOLD, "sinc_dvr_small.npz"))
+    dev = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()  # noqa: E731
+    u2d, C, Ct = dev(g["u2d"]), dev(g["C"]), dev(g["C_tilde"])
+    for got, key in (
+        (K.two_body_from_grid(u2d, C), "u_default_bra"),
+        (K.two_body_from_grid(u2d, C, Ct), "u_ctilde"),
+        (K.two_body_from_grid(u2d, C, Ct, antisymmetrize=True), "u_ctilde_as"),
+    ):
+        ref = g[key]
+        assert np.abs(got.cpu().numpy() - ref).max() <= 1e-12 * np.abs(ref).max()
+
+
+@pytest.mark.parametrize("cplx", [False, True])
+def test_two_body_from_grid_vs_oracle_larger(cplx):
+    from quantum_systems_amd import kernels as K
+
+    rng = np.random.default_rng(3 + cplx)
+    N, M = 301, 24
+    x = np.linspace(-8, 8, N)
+    Kmat = 1.0 / np.sqrt((x[:, None] - x[None, :]) ** 2 + 0.0625)
+    C = rng.standard_normal((N, M)) / np.sqrt(N)
+    if cplx:
+        C = C + 1j * rng.standard_normal((N, M)) / np.sqrt(N)
+    ref = orc.two_body_from_grid(Kmat, C)
+    got = K.two_body_from_grid(torch.from_numpy(Kmat).cuda(), torch.from_numpy(C).cuda()).cpu().numpy()
+    assert np.abs(got - ref).max() <= 1e-12 * np.abs(ref).max()
