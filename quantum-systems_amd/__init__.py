@@ -18,6 +18,7 @@ from .custom_system import construct_custom_system, setup_basis_set
 from .general_orbital_system import GeneralOrbitalSystem
 from .one_dim_qd import ODQD
 from .random_basis import RandomBasisSet
+from .sinc_dvr import ODSincDVR
 from .spatial_orbital_system import SpatialOrbitalSystem
 from .system import QuantumSystem
 from .two_dim_ho import TwoDimensionalHarmonicOscillator
@@ -25,6 +26,6 @@ from .two_dim_ho import TwoDimensionalHarmonicOscillator
 __all__ = [
     "BasisSet", "RandomBasisSet", "QuantumSystem", "SpatialOrbitalSystem",
     "GeneralOrbitalSystem", "setup_basis_set", "construct_custom_system",
-    "TwoDimensionalHarmonicOscillator", "ODQD",
+    "TwoDimensionalHarmonicOscillator", "ODQD", "ODSincDVR",
     "hip", "DeviceModule", "DeviceArray", "kernels", "sharded",
 ]

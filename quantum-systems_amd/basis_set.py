@@ -283,15 +283,11 @@ class BasisSet:
         # :368-372 transforms spin_x/y/z/spin_2 into a loop local and drops
         # the result; they keep their old values (and shapes) here as well.
 
-        old_u = self._u
-        self._u = None  # let the old tensor go as soon as the new one exists
-        self.u = _deliver(kernels.transform_two_body(_stage(old_u), d_C, d_Ct), np)
-        del old_u
+        # through the (overridable) method, as :374-382 does -- ODSincDVR replaces it and looks
+        # at the stored u while doing so; the old tensor is released when the attribute is rebound
+        self.u = self.transform_two_body_elements(self._u, d_C, np, C_tilde=d_Ct)
         if self.spin_2_tb is not None:                          # :379-382
-            old = self._spin_2_tb
-            self._spin_2_tb = None
-            self.spin_2_tb = _deliver(kernels.transform_two_body(_stage(old), d_C, d_Ct), np)
-            del old
+            self.spin_2_tb = self.transform_two_body_elements(self._spin_2_tb, d_C, np, C_tilde=d_Ct)
 
         if self.position is not None:
             self.position = one_body(self.position)             # stacked (dim, l, l)

@@ -108,3 +108,30 @@ def test_two_body_from_grid_vs_oracle_larger(cplx):
     ref = orc.two_body_from_grid(Kmat, C)
     got = K.two_body_from_grid(torch.from_numpy(Kmat).cuda(), torch.from_numpy(C).cuda()).cpu().numpy()
     assert np.abs(got - ref).max() <= 1e-12 * np.abs(ref).max()
+
+
+def test_sinc_dvr_change_basis_like_reference():
+    # SpatialOrbitalSystem(n, ODSincDVR).change_basis: the 2-d u becomes the rank-4 tensor of
+    # sinc_dvr.py:238-246; golden vectors from the reference class itself
+    import quantum_systems_amd as qsa
+
+    g = np.load(os.path.join(GOLD, "sinc_dvr_small.npz"))
+    C, Ct = g["C"], g["C_tilde"]
+    for bra, key in ((None, "u_default_bra"), (Ct, "u_ctilde")):
+        spas = qsa.SpatialOrbitalSystem(2, qsa.ODSincDVR(12, 6.0, potential=qsa.ODSincDVR.HOPotential(0.5)))
+        spas.change_basis(C, C_tilde=bra)
+        assert spas.l == 7 and H(spas.u).shape == (7, 7, 7, 7)
+        ref = g[key]
+        assert np.abs(H(spas.u) - ref).max() <= 1e-12 * np.abs(ref).max()
+        h_ref = (C.conj().T if bra is None else bra) @ g["h"] @ C
+        np.testing.assert_allclose(H(spas.h), h_ref, rtol=1e-12, atol=1e-12)
+    dvr = qsa.ODSincDVR(12, 6.0, potential=qsa.ODSincDVR.HOPotential(0.5))
+    got = dvr.transform_two_body_elements(dvr.u, C, np, anti_symmetrize=True, C_tilde=Ct)
+    ref = g["u_ctilde_as"]
+    assert np.abs(H(got) - ref).max() <= 1e-12 * np.abs(ref).max()
+    # the 4-d representation goes through the ordinary four-index transform and agrees
+    d4 = qsa.ODSincDVR(12, 6.0, potential=qsa.ODSincDVR.HOPotential(0.5), u_repr="4d")
+    got4 = d4.transform_two_body_elements(d4.u, C, np, C_tilde=Ct)
+    assert np.abs(H(got4) - g["u_ctilde"]).max() <= 1e-12 * np.abs(g["u_ctilde"]).max()
+    with pytest.raises(AssertionError):
+        d4.transform_two_body_elements(d4.u, C, np, anti_symmetrize=True)

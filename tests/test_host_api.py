@@ -3,6 +3,7 @@ shape-checking setters, sizes, module plumbing, deep copies, error behaviour.
 Nothing here computes a transform (that needs the GPU and is covered by
 ``-m gpu`` tests); restated from the reference's tests where one exists."""
 
+import os
 import warnings
 
 import numpy as np
@@ -191,3 +192,39 @@ def test_general_system_requires_n_le_l():
     assert gos.n == 2 and gos.m == 0
     with pytest.raises(AssertionError):
         GeneralOrbitalSystem(3, bs)
+
+
+# ------------------------------------------------------------------ ODSincDVR (host-side behaviour)
+
+
+def test_sinc_dvr_construction_matches_reference_class():
+    import warnings
+
+    import quantum_systems_amd as qsa
+
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "sinc_dvr_small.npz"))
+    dvr = qsa.ODSincDVR(12, 6.0, potential=qsa.ODSincDVR.HOPotential(0.5))
+    for name, key in (("h", "h"), ("s", "s"), ("spf", "spf"), ("position", "position"), ("u", "u2d")):
+        got = np.asarray(getattr(dvr, name))
+        assert got.dtype == np.complex128
+        np.testing.assert_allclose(got, g[key], rtol=1e-13, atol=1e-13)
+    np.testing.assert_allclose(dvr.grid, g["grid"])
+    assert dvr.u_repr == "2d" and dvr.sparse_repr and dvr.num_grid_points == 12
+    # what the reference class does not do, it does not do here either
+    dvr.set_u_repr("4d")
+    assert dvr.u_repr == "2d"                                  # built, not stored (sinc_dvr.py:118-138)
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        dvr.change_module(np)
+    assert len(w) == 1 and "sparse u" in str(w[0].message)
+    with pytest.raises(TypeError):                              # no spinor arguments (:180-188)
+        qsa.GeneralOrbitalSystem(2, dvr)
+    with pytest.raises(ValueError):
+        qsa.ODSincDVR(4, 1.0, u_repr="3d")
+    d4 = qsa.ODSincDVR(5, 3.0, u_repr="4d")
+    assert d4.u_repr == "4d" and not d4.sparse_repr
+    idx = np.arange(5)
+    u4 = np.asarray(d4.u)
+    K = 1.0 / np.sqrt((d4.grid[:, None] - d4.grid[None, :]) ** 2 + 0.25**2)
+    np.testing.assert_allclose(u4[idx[:, None], idx[None, :], idx[:, None], idx[None, :]], K)
+    assert np.count_nonzero(u4) == 25
