@@ -381,7 +381,7 @@ def main():
     roofline = {
         "bound": "mfma", "achieved": achieved, "peak": MFMA_F64_PEAK_TFLOPS, "unit": "TFLOP/s",
         "frac": achieved / MFMA_F64_PEAK_TFLOPS, "traffic": None,
-        "kernel": "qs::gemm_fast_kernel<false,4,4> (v_mfma_f64_16x16x4_f64; qs::gemm_kernel for non-tile-multiple l)",
+        "kernel": "qs::gemm_fast_kernel<false, 4, 4, true, false> (v_mfma_f64_16x16x4_f64; exact 128x128 tiles at l = 256)",
         "flops_per_launch": flops / world / launches_per_step,
         "avg_launch_ms": per_launch_s * 1e3,
     }
