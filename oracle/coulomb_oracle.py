@@ -69,3 +69,80 @@ def coulomb_elements(l, p_lo=0, p_hi=None):
     out = np.empty((p_hi - p_lo, l, l, l))
     _load().tdho_coulomb_elements(l, p_lo, p_hi, out.ctypes.data)
     return out
+
+
+# --------------------------------------------------------------------------
+# One-body side of the 2-D dots: orbitals on the polar grid, dipole elements and
+# the double-well Hamiltonian.  Radial integrals by symbolic integration, as the
+# reference does them (two_dim_helper.py:50-67) -- the product evaluates the
+# same integrals in closed form, so the two are independent.
+# --------------------------------------------------------------------------
+
+
+def spf_norm(n, m, mass=1, omega=1):
+    """two_dim_helper.py:26-33."""
+    from scipy.special import factorial
+
+    return np.sqrt(mass * omega) * np.sqrt(factorial(n) / (np.pi * factorial(n + abs(m))))
+
+
+def radial_integral(n_p, m_p, n_q, m_q, mass=1, omega=1, order=1):
+    """int_0^inf r^(1+order) R_p R_q dr, symbolically (two_dim_helper.py:50-67)."""
+    import sympy
+
+    a = sympy.Float(np.sqrt(mass * omega))
+    r = sympy.Symbol("r", positive=True)
+
+    def radial(n, m):
+        return (a * r) ** abs(m) * sympy.assoc_laguerre(n, abs(m), a**2 * r**2) * sympy.exp(-(a**2) * r**2 / 2)
+
+    return float(sympy.integrate(r * r**order * radial(n_p, m_p) * radial(n_q, m_q), (r, 0, sympy.oo)))
+
+
+def spf_table(l, radius, theta, mass=1, omega=1):
+    """Orbitals on meshgrid(radius, theta) (two_dim_ho.py:96-108, two_dim_helper.py:16-50)."""
+    from scipy.special import assoc_laguerre
+
+    R, T = np.meshgrid(radius, theta)
+    a = np.sqrt(mass * omega)
+    out = np.zeros((l,) + R.shape, dtype=np.complex128)
+    for p in range(l):
+        n, m = indices_nm(p)
+        out[p] = (spf_norm(n, m, mass, omega) * np.exp(1j * m * T) * (a * R) ** abs(m)
+                  * assoc_laguerre(a**2 * R**2, n, abs(m)) * np.exp(-(a**2) * R**2 / 2.0))
+    return out
+
+
+def position_integrals(l, mass=1, omega=1):
+    """<p|x|q>, <p|y|q> (two_dim_ho.py:113-139; angular factors two_dim_helper.py:78-89)."""
+    pos = np.zeros((2, l, l), dtype=np.complex128)
+    for p in range(l):
+        n_p, m_p = indices_nm(p)
+        for q in range(l):
+            n_q, m_q = indices_nm(q)
+            if abs(m_p - m_q) != 1:
+                continue
+            amp = spf_norm(n_p, m_p, mass, omega) * spf_norm(n_q, m_q, mass, omega) * radial_integral(
+                n_p, m_p, n_q, m_q, mass, omega)
+            pos[0, p, q] = amp * np.pi
+            pos[1, p, q] = amp * (-(m_p - m_q) * 1j * np.pi)
+    return pos
+
+
+def double_well_one_body(l, omega, mass, barrier_strength, axis=0):
+    """two_dim_helper.py:304-339 (angular factors :92-105)."""
+    h = np.zeros((l, l), dtype=np.complex128)
+    for p in range(l):
+        n_p, m_p = indices_nm(p)
+        h[p, p] += omega * shell_energy(n_p, m_p) + omega**2 * barrier_strength**2 / 8.0
+        for q in range(l):
+            n_q, m_q = indices_nm(q)
+            d = m_p - m_q
+            if abs(d) % 2 == 1:
+                continue
+            ang = 4 / (1 - d**2)
+            if axis == 0 and (abs(d) // 2) % 2 == 1:
+                ang = -ang
+            h[p, q] -= (0.5 * omega**2 * barrier_strength * spf_norm(n_p, m_p, mass, omega)
+                        * spf_norm(n_q, m_q, mass, omega) * radial_integral(n_p, m_p, n_q, m_q, mass, omega) * ang)
+    return h

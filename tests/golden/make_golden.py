@@ -368,7 +368,46 @@ def case_odqd():
          u_ctilde_as=dvr.transform_two_body_elements(dvr.u, C, np, anti_symmetrize=True, C_tilde=Ct))
 
 
+def case_tdho_one_body():
+    """One-body side of the 2-D dots from the reference's own functions: double-well Hamiltonians,
+    the orbital table and dipole elements of a small oscillator (the class methods are run on a bare
+    instance so that the interpreter-mode Coulomb generator is not needed), the eigenvalues its test
+    quotes (tests/test_two_dim_dw.py:93-112) and its double-well regression files
+    (tests/dat/tddw_{h,u,dipole_moment}.npy; u as a seeded sample + absolute sum)."""
+    from quantum_systems.quantum_dots.two_dim import two_dim_helper as hlp
+    from quantum_systems.quantum_dots.two_dim.two_dim_ho import TwoDimensionalHarmonicOscillator as TDHO
+
+    out = {}
+    for tag, (l, omega, mass, b, axis) in {"a": (10, 0.8, 1, 3, 0), "b": (12, 1.0, 1, 2, 1), "c": (6, 1.0, 1, 2, 1),
+                                            "d": (8, 0.5, 2.0, 1.5, 0)}.items():
+        out[f"dw_{tag}_params"] = np.array([l, omega, mass, b, axis], dtype=float)
+        out[f"dw_{tag}_h"] = hlp.get_double_well_one_body_elements(l, omega, mass, b, dtype=np.complex128, axis=axis)
+    out["smooth_params"] = np.array([6, 1.0, 1.0, 2.0, 2.0])
+    out["smooth_h"] = hlp.get_smooth_double_well_one_body_elements(6, 1.0, 1.0, a=2.0, b=2.0, dtype=np.complex128)
+    out["test_energies_l6_b2_axis1"] = np.array([0.81129823, 1.37162083, 1.93581042, 2.21403823, 2.37162083, 2.93581042])
+    bare = object.__new__(TDHO)
+    bare.l, bare.mass, bare.omega, bare.num_grid_points, bare.np = 10, 1, 0.8, 21, np
+    bare.radius = np.linspace(0, 4, 21)
+    bare.theta = np.linspace(0, 2 * np.pi, 21)
+    TDHO.setup_spf(bare)
+    TDHO.construct_position_integrals(bare)
+    out["tdho_l10_spf"], out["tdho_l10_position"] = bare._spf, bare._position
+    out["tdho_l10_params"] = np.array([10, 4.0, 21, 0.8, 1.0])
+    rng = np.random.default_rng(11)
+    dat = "/root/reference/tests/dat"
+    u = np.load(os.path.join(dat, "tddw_u.npy"))
+    ui = rng.integers(0, u.shape[0], size=(4000, 4))
+    out.update(tddw_h=np.load(os.path.join(dat, "tddw_h.npy")),
+               tddw_dipole_moment=np.load(os.path.join(dat, "tddw_dipole_moment.npy")),
+               tddw_u_idx=ui, tddw_u_val=u[tuple(ui.T)], tddw_u_abs_sum=np.abs(u).sum(),
+               tddw_u_shape=np.array(u.shape))
+    save("tdho_one_body", **out)
+
+
 if __name__ == "__main__":
+    if len(sys.argv) > 1 and sys.argv[1] == "tdho1":
+        case_tdho_one_body()
+        sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "tdho":
         case_tdho_coulomb()
         sys.exit(0)
@@ -383,3 +422,4 @@ if __name__ == "__main__":
     case_change_basis_with_spf()
     case_tdho_coulomb()
     case_odqd()
+    case_tdho_one_body()

@@ -3,6 +3,7 @@ oracle, the reference's own table and reference-computed spot values; then
 BASELINE.json configs[1] end to end: 10 shells (l = 55), fp64 change of basis on
 the GPU."""
 
+import os
 import time
 
 import numpy as np
@@ -11,6 +12,8 @@ import torch
 
 from oracle import coulomb_oracle as co
 from oracle import qs_oracle as orc
+
+import quantum_systems_amd as qsa  # noqa: E402
 
 pytestmark = pytest.mark.gpu
 
@@ -89,3 +92,43 @@ def test_config2_quantum_dot_ten_shells(td, mod):
     e1 = complex(qsa.array_module.to_host(spas.compute_reference_energy()))
     assert abs(e0 - e1) <= 1e-9 * abs(e0)
     print(f"generated l=55 Coulomb elements in {gen_s:.2f} s ({mod})")
+
+
+def test_tdho_spf_table_and_dipole_like_reference():
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "tdho_one_body.npz"))
+    l, radius, n, omega, mass = g["tdho_l10_params"]
+    bs = qsa.TwoDimensionalHarmonicOscillator(int(l), radius, int(n), omega=omega, mass=mass)
+    np.testing.assert_allclose(np.asarray(bs.spf), g["tdho_l10_spf"], rtol=1e-12, atol=1e-13)
+    np.testing.assert_allclose(np.asarray(bs.position), g["tdho_l10_position"], rtol=1e-11, atol=1e-12)
+    assert np.asarray(bs.spf).shape == (10, 21, 21)
+
+
+def test_tddw_like_reference():
+    # tests/test_two_dim_dw.py:166-215: GeneralOrbitalSystem(2, TwoDimensionalDoubleWell(10, 8, 201,
+    # barrier_strength=3, omega=0.8, axis=0)) rotated into the eigenbasis of its one-body Hamiltonian,
+    # against the reference's own regression files (h, dipole in full; u sampled + absolute sum)
+    from quantum_systems_amd import two_dim_ho as td
+
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "tdho_one_body.npz"))
+    tddw = qsa.GeneralOrbitalSystem(
+        2, qsa.TwoDimensionalDoubleWell(10, 8, 201, barrier_strength=3, omega=0.8, axis=0))
+    h_dw = td.get_double_well_one_body_elements(10, 0.8, 1, 3, dtype=np.complex128, axis=0)
+    _, C_dw = np.linalg.eigh(h_dw)
+    C = np.kron(C_dw, np.eye(2))
+    tddw.change_basis(C[:, : tddw.l])
+    H = qsa.array_module.to_host
+    np.testing.assert_allclose(np.abs(g["tddw_dipole_moment"]), np.abs(np.asarray(H(tddw.dipole_moment))), atol=1e-10)
+    np.testing.assert_allclose(g["tddw_h"], np.asarray(H(tddw.h)), atol=1e-10)
+    u = np.asarray(H(tddw.u))
+    assert u.shape == tuple(g["tddw_u_shape"])
+    ui = g["tddw_u_idx"]
+    np.testing.assert_allclose(np.abs(g["tddw_u_val"]), np.abs(u[tuple(ui.T)]), atol=1e-10)
+    np.testing.assert_allclose(g["tddw_u_abs_sum"], np.abs(u).sum(), rtol=1e-9)
+
+
+def test_zero_barrier_reproduces_the_oscillator():
+    # tests/test_two_dim_dw.py:72-90
+    tddw = qsa.TwoDimensionalDoubleWell(12, 10, 41, barrier_strength=0, axis=0)
+    tdho = qsa.TwoDimensionalHarmonicOscillator(12, 10, 41)
+    for name in ("h", "u", "spf"):
+        np.testing.assert_allclose(np.asarray(getattr(tddw, name)), np.asarray(getattr(tdho, name)), atol=1e-7)

@@ -228,3 +228,37 @@ def test_sinc_dvr_construction_matches_reference_class():
     K = 1.0 / np.sqrt((d4.grid[:, None] - d4.grid[None, :]) ** 2 + 0.25**2)
     np.testing.assert_allclose(u4[idx[:, None], idx[None, :], idx[:, None], idx[None, :]], K)
     assert np.count_nonzero(u4) == 25
+
+
+# ------------------------------------------------------------------ 2-D dots: host-side one-body generators
+
+
+def test_two_dim_one_body_generators_match_reference():
+    from quantum_systems_amd import two_dim_ho as td
+
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "tdho_one_body.npz"))
+    for tag in "abcd":
+        l, omega, mass, b, axis = g[f"dw_{tag}_params"]
+        h = td.get_double_well_one_body_elements(int(l), omega, mass, b, dtype=np.complex128, axis=int(axis))
+        np.testing.assert_allclose(h, g[f"dw_{tag}_h"], rtol=1e-11, atol=1e-12)
+    l, omega, mass, a, b = g["smooth_params"]
+    np.testing.assert_allclose(
+        td.get_smooth_double_well_one_body_elements(int(l), omega, mass, a=a, b=b, dtype=np.complex128),
+        g["smooth_h"], rtol=1e-11, atol=1e-12)
+    # eigenvalues quoted by the reference's test (tests/test_two_dim_dw.py:93-112)
+    eps = np.linalg.eigvalsh(td.get_double_well_one_body_elements(6, 1, 1, 2, dtype=np.complex128, axis=1))
+    np.testing.assert_allclose(eps[:6], g["test_energies_l6_b2_axis1"], rtol=1e-7)
+    # angular integrals against their definitions (tests/test_two_dim_dw.py:18-69 uses closed forms
+    # from a CAS; here: numerical quadrature of |cos| and |sin| between plane waves)
+    t = np.linspace(0, 2 * np.pi, 200001)
+    for mp in range(-4, 5):
+        for mq in range(-4, 5):
+            f = np.exp(-1j * mp * t) * np.exp(1j * mq * t)
+            assert abs(np.trapezoid(f * abs(np.cos(t)), t) - td.theta_1_tilde_integral(mp, mq)) < 1e-6
+            assert abs(np.trapezoid(f * abs(np.sin(t)), t) - td.theta_2_tilde_integral(mp, mq)) < 1e-6
+    # closed-form radial moments against quadrature
+    r = np.linspace(0, 30, 600001)
+    for (n_p, m_p, n_q, m_q, order) in [(0, 0, 0, 0, 1), (1, -2, 0, 2, 1), (2, 1, 1, 1, 4), (3, 0, 2, -3, 2)]:
+        f = r ** (1 + order) * td.spf_radial(r, n_p, m_p, 1.3, 0.7) * td.spf_radial(r, n_q, m_q, 1.3, 0.7)
+        np.testing.assert_allclose(td.radial_integral(n_p, m_p, n_q, m_q, 1.3, 0.7, order=order),
+                                   np.trapezoid(f, r), rtol=1e-8)

@@ -53,3 +53,25 @@ def test_full_table_of_the_reference(golden):
 def test_slab_form_matches_full():
     full = co.coulomb_elements(10)
     np.testing.assert_array_equal(co.coulomb_elements(10, 3, 7), full[3:7])
+
+
+# ---- one-body side: double-well Hamiltonian, orbital table, dipole elements
+
+
+def test_double_well_one_body_oracle_matches_reference(golden):
+    g = golden("tdho_one_body")
+    for tag in "acd":                      # (b: l = 12 takes the symbolic route ~10 s; covered by the product test)
+        l, omega, mass, b, axis = g[f"dw_{tag}_params"]
+        h = co.double_well_one_body(int(l), omega, mass, b, axis=int(axis))
+        np.testing.assert_allclose(h, g[f"dw_{tag}_h"], rtol=1e-11, atol=1e-12)
+    # reference tests/test_two_dim_dw.py:93-112
+    eps = np.linalg.eigvalsh(co.double_well_one_body(6, 1.0, 1, 2, axis=1))
+    np.testing.assert_allclose(eps[:6], g["test_energies_l6_b2_axis1"], rtol=1e-7)
+
+
+def test_spf_table_and_dipole_oracle_match_reference(golden):
+    g = golden("tdho_one_body")
+    l, radius, n, omega, mass = g["tdho_l10_params"]
+    spf = co.spf_table(int(l), np.linspace(0, radius, int(n)), np.linspace(0, 2 * np.pi, int(n)), mass, omega)
+    np.testing.assert_allclose(spf, g["tdho_l10_spf"], rtol=1e-12, atol=1e-13)
+    np.testing.assert_allclose(co.position_integrals(int(l), mass, omega), g["tdho_l10_position"], rtol=1e-11, atol=1e-12)
