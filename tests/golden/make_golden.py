@@ -401,6 +401,16 @@ def case_tdho_one_body():
                tddw_dipole_moment=np.load(os.path.join(dat, "tddw_dipole_moment.npy")),
                tddw_u_idx=ui, tddw_u_val=u[tuple(ui.T)], tddw_u_abs_sum=np.abs(u).sum(),
                tddw_u_shape=np.array(u.shape))
+    # the reference's orbital tables tests/dat/2d-ho-qd-spf-p=*.dat (radius 4, 101 x 101 points,
+    # tests/conftest.py:155-168): 600 seeded grid points per orbital + the absolute sum of each table
+    pts = np.stack([rng.integers(0, 101, 600), rng.integers(0, 101, 600)], axis=1)
+    vals, sums = [], []
+    for p in range(15):
+        tab = np.loadtxt(os.path.join(dat, f"2d-ho-qd-spf-p={p}.dat")).view(complex)
+        vals.append(tab[tuple(pts.T)])
+        sums.append(np.abs(tab).sum())
+    out.update(spf_files_pts=pts, spf_files_val=np.array(vals), spf_files_abs_sum=np.array(sums),
+               spf_files_shape=np.array(tab.shape))
     save("tdho_one_body", **out)
 
 

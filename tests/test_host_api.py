@@ -262,3 +262,10 @@ def test_two_dim_one_body_generators_match_reference():
         f = r ** (1 + order) * td.spf_radial(r, n_p, m_p, 1.3, 0.7) * td.spf_radial(r, n_q, m_q, 1.3, 0.7)
         np.testing.assert_allclose(td.radial_integral(n_p, m_p, n_q, m_q, 1.3, 0.7, order=order),
                                    np.trapezoid(f, r), rtol=1e-8)
+    # orbital tables against the reference's files (tests/test_two_dim_ho.py:93-100)
+    R, T = np.meshgrid(np.linspace(0, 4, 101), np.linspace(0, 2 * np.pi, 101))
+    pts = g["spf_files_pts"]
+    for p in range(15):
+        tab = td.spf_state(R, T, p, 1, 1)
+        np.testing.assert_allclose(tab[tuple(pts.T)], g["spf_files_val"][p], rtol=1e-7, atol=1e-12)
+        np.testing.assert_allclose(np.abs(tab).sum(), g["spf_files_abs_sum"][p], rtol=1e-9)

@@ -75,3 +75,15 @@ def test_spf_table_and_dipole_oracle_match_reference(golden):
     spf = co.spf_table(int(l), np.linspace(0, radius, int(n)), np.linspace(0, 2 * np.pi, int(n)), mass, omega)
     np.testing.assert_allclose(spf, g["tdho_l10_spf"], rtol=1e-12, atol=1e-13)
     np.testing.assert_allclose(co.position_integrals(int(l), mass, omega), g["tdho_l10_position"], rtol=1e-11, atol=1e-12)
+
+
+def test_spf_tables_match_the_reference_files(golden):
+    # reference tests/test_two_dim_ho.py:93-100 with tests/conftest.py:155-168 (radius 4, 101 points)
+    g = golden("tdho_one_body")
+    grid_r, grid_t = np.linspace(0, 4, 101), np.linspace(0, 2 * np.pi, 101)
+    spf = co.spf_table(15, grid_r, grid_t)
+    assert spf.shape[1:] == tuple(g["spf_files_shape"])
+    pts = g["spf_files_pts"]
+    for p in range(15):
+        np.testing.assert_allclose(spf[p][tuple(pts.T)], g["spf_files_val"][p], rtol=1e-7, atol=1e-12)
+        np.testing.assert_allclose(np.abs(spf[p]).sum(), g["spf_files_abs_sum"][p], rtol=1e-9)
