@@ -132,3 +132,24 @@ def test_zero_barrier_reproduces_the_oscillator():
     tdho = qsa.TwoDimensionalHarmonicOscillator(12, 10, 41)
     for name in ("h", "u", "spf"):
         np.testing.assert_allclose(np.asarray(getattr(tddw, name)), np.asarray(getattr(tdho, name)), atol=1e-7)
+
+
+def test_change_of_basis_like_reference():
+    # tests/test_two_dim_dw.py:115-160: the oscillator system rotated with the eigenvectors of the
+    # double-well one-body Hamiltonian carries the same u and orbitals as the double-well system
+    from quantum_systems_amd import two_dim_ho as td
+
+    l, grid = 12, 41
+    tdho = qsa.GeneralOrbitalSystem(2, qsa.TwoDimensionalHarmonicOscillator(l, 10, grid, omega=1))
+    h_dw = td.get_double_well_one_body_elements(l, 1, 1, 3, dtype=np.complex128, axis=0)
+    _, C_dw = np.linalg.eigh(h_dw)
+    C = qsa.BasisSet.add_spin_one_body(C_dw, np=np)
+    tdho.change_basis(C)
+    tddw = qsa.GeneralOrbitalSystem(
+        2, qsa.TwoDimensionalDoubleWell(l, 10, grid, omega=1, mass=1, barrier_strength=3, axis=0))
+    tddw.change_basis(C)
+    np.testing.assert_allclose(np.asarray(tdho.u), np.asarray(tddw.u), atol=1e-7)
+    np.testing.assert_allclose(np.asarray(tdho.spf), np.asarray(tddw.spf), atol=1e-7)
+    # and the rotated double-well h is diagonal with the double-well energies (spin doubled)
+    eps = np.linalg.eigvalsh(h_dw)
+    np.testing.assert_allclose(np.asarray(tddw.h), np.diag(np.repeat(eps, 2)), atol=1e-9)
