@@ -22,32 +22,39 @@ class RandomBasisSet(BasisSet):
         self.setup_basis()
 
     def setup_basis(self):
-        np, l = self.np, self.l
-        self.h = self.make_hermitian(self.get_random_elements((l, l), np))
-        self.s = self.make_hermitian(self.get_random_elements((l, l), np))
-        self.u = self.make_two_body_symmetry(self.get_random_elements((l, l, l, l), np))
-        self.position = self.make_position_elements_hermitian(
-            self.get_random_elements((self.dim, l, l), np)
-        )
-        self.nuclear_repulsion_energy = np.random.random()
-        self.charge = np.random.choice([-1, 1])
+        """Draw order matters for reproducing a seeded stream: h, s, u,
+        position, then the two scalars (random_basis.py:21-35)."""
+        l = self.l
+        draws = {}
+        for name, shape in (("h", (l, l)), ("s", (l, l)), ("u", (l,) * 4), ("position", (self.dim, l, l))):
+            draws[name] = self.get_random_elements(shape, self.np)
+        self.h = self.make_hermitian(draws["h"])
+        self.s = self.make_hermitian(draws["s"])
+        self.u = self.make_two_body_symmetry(draws["u"])
+        self.position = self.make_position_elements_hermitian(draws["position"])
+        rng = self.np.random
+        self.nuclear_repulsion_energy = rng.random()
+        self.charge = rng.choice([-1, 1])
 
     @staticmethod
     def make_hermitian(h):
-        return 0.5 * (h + h.conj().T)
+        """(h + h^dagger) / 2"""
+        return (h + h.conj().T) * 0.5
 
     @staticmethod
     def make_position_elements_hermitian(position):
-        for axis in range(len(position)):
-            position[axis] = RandomBasisSet.make_hermitian(position[axis])
+        """Every axis made Hermitian, in place (the argument is returned)."""
+        position[...] = (position + position.conj().transpose(0, 2, 1)) * 0.5
         return position
 
     @staticmethod
     def make_two_body_symmetry(u):
-        return 0.5 * (u + u.transpose(1, 0, 3, 2))
+        """u_pqrs = u_qpsr: particle-exchange symmetry."""
+        return (u + u.transpose(1, 0, 3, 2)) * 0.5
 
     @staticmethod
     def get_random_elements(shape, np):
         """Complex array, real and imaginary parts uniform on [0, 1), real part
         drawn first (random_basis.py:52-69)."""
-        return np.random.random(shape) + 1j * np.random.random(shape)
+        real = np.random.random(shape)
+        return real + np.random.random(shape) * 1j
