@@ -161,6 +161,65 @@ def transform_two_body(u, C, C_tilde=None, out=None):
     return out
 
 
+class TransformPlan:
+    """The four-index transform of a RESIDENT ``u`` captured once as a HIP graph,
+    for loops that transform every step with new coefficients (the
+    time-propagation pattern of BASELINE.json configs[4]: ``C(t)`` changes, ``u``
+    stays).  At small l a transform is a handful of 10 us kernels and the host
+    side of each call (argument checks, ctypes, allocator) costs as much as the
+    GPU work; a graph replay is one launch.
+
+        plan = TransformPlan(u, C)          # u (L,L,L,L), C (L,M), C_tilde optional
+        for step in ...:
+            plan.C.copy_(C_t)               # update the static coefficient buffers in place
+            plan.C_tilde.copy_(Ct_t)
+            out = plan.replay()             # valid until the next replay
+
+    The captured launches are exactly those of ``transform_two_body``
+    (``qs_transform_two_body`` on the capture stream); buffers, workspace and the
+    output are owned by the plan."""
+
+    def __init__(self, u, C, C_tilde=None):
+        lib = _lib.load()
+        if C_tilde is None:
+            C_tilde = default_bra(C)
+        dt = result_dtype(u, C, C_tilde)
+        self.u = _dev(u, dt)
+        self.C = _dev(C, dt).clone()
+        self.C_tilde = _dev(C_tilde, dt).clone()
+        L, M = self.C.shape
+        if tuple(self.u.shape) != (L, L, L, L) or tuple(self.C_tilde.shape) != (M, L):
+            raise ValueError("operand shapes do not match C")
+        code = dtype_code(dt)
+        nbytes = check(lib.qs_transform_two_body_workspace(code, L, M), "workspace query")
+        self.out = torch.empty((M, M, M, M), dtype=dt, device=self.u.device)
+        self._work = torch.empty(int(nbytes), dtype=torch.uint8, device=self.u.device)
+
+        def launch():
+            check(
+                lib.qs_transform_two_body(
+                    code, self.u.data_ptr(), self.C.data_ptr(), self.C_tilde.data_ptr(),
+                    self.out.data_ptr(), self._work.data_ptr(), self._work.numel(), L, M, _stream(),
+                ),
+                "qs_transform_two_body",
+            )
+
+        # one eager run on a side stream (first-launch set-up: function attributes, device
+        # properties), then the capture
+        side = torch.cuda.Stream(device=self.u.device)
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            launch()
+        torch.cuda.current_stream().wait_stream(side)
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph):
+            launch()
+
+    def replay(self):
+        self.graph.replay()
+        return self.out
+
+
 def transform_two_body_partial(u_slab, C, C_tilde=None, out=None):
     """Contractions over d, c, b of a leading-index slab:
     v[a,q,r,s] = Ct[qb] u[a,b,c,d] C[cr] C[ds] for the rows of the slab."""
