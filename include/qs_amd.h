@@ -177,6 +177,18 @@ int qs_tdho_coulomb_elements(void* out, int64_t l, int64_t p_lo, int64_t p_hi,
                              void* stream);
 
 /*
+ * The same elements for an explicit orbital table: nm_table is a device array
+ * of 2*l int32, n of every orbital followed by m of every orbital; max_shell =
+ * max(2 n + |m| + 1) over the table (the caller knows it; the log-factorial
+ * tables cover max_shell <= 30).  Replaces get_coulomb_elements_B,
+ * two_dim_helper.py:284-301 (orbitals ordered by their energy in a magnetic
+ * field, TwoDimHarmonicOscB, two_dim_ho.py:213-276).
+ */
+int qs_tdho_coulomb_elements_nm(void* out, const void* nm_table, int64_t l,
+                                int64_t max_shell, int64_t p_lo, int64_t p_hi,
+                                void* stream);
+
+/*
  * Auxiliary entry points (no reference counterpart).
  *   qs_tuning_set: override a kernel choice for tuning runs; keys
  *     "gemm_f64_cfg", "gemm_c128_cfg" (tile shape of the general

@@ -146,3 +146,17 @@ def double_well_one_body(l, omega, mass, barrier_strength, axis=0):
             h[p, q] -= (0.5 * omega**2 * barrier_strength * spf_norm(n_p, m_p, mass, omega)
                         * spf_norm(n_q, m_q, mass, omega) * radial_integral(n_p, m_p, n_q, m_q, mass, omega) * ang)
     return h
+
+
+def coulomb_element_nm(nm, p, q, r, s):
+    """One element for an explicit orbital table (two_dim_helper.py:284-301)."""
+    (n_p, m_p), (n_q, m_q), (n_r, m_r), (n_s, m_s) = nm[p], nm[q], nm[r], nm[s]
+    return coulomb_ho(int(n_p), int(m_p), int(n_q), int(m_q), int(n_r), int(m_r), int(n_s), int(m_s))
+
+
+def level_table(n_array, m_array, omega_c=0.0, omega=1.0):
+    """Rows (n, m, E) of the reference's frame: sorted by E = omega (2n+|m|+1) - omega_c m / 2,
+    ties by m (two_dim_helper.py:271-272, :380-392)."""
+    rows = [(float(n), float(m), omega * (2 * n + abs(m) + 1) - (omega_c * m) / 2) for n in n_array for m in m_array]
+    rows.sort(key=lambda t: (t[2], t[1]))
+    return np.array([(int(n), int(m)) for n, m, _ in rows]), np.array([e for _, _, e in rows])

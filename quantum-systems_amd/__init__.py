@@ -21,11 +21,11 @@ from .random_basis import RandomBasisSet
 from .sinc_dvr import ODSincDVR
 from .spatial_orbital_system import SpatialOrbitalSystem
 from .system import QuantumSystem
-from .two_dim_ho import TwoDimensionalDoubleWell, TwoDimensionalHarmonicOscillator
+from .two_dim_ho import TwoDimensionalDoubleWell, TwoDimensionalHarmonicOscillator, TwoDimHarmonicOscB
 
 __all__ = [
     "BasisSet", "RandomBasisSet", "QuantumSystem", "SpatialOrbitalSystem",
     "GeneralOrbitalSystem", "setup_basis_set", "construct_custom_system",
-    "TwoDimensionalHarmonicOscillator", "TwoDimensionalDoubleWell", "ODQD", "ODSincDVR",
+    "TwoDimensionalHarmonicOscillator", "TwoDimensionalDoubleWell", "TwoDimHarmonicOscB", "ODQD", "ODSincDVR",
     "hip", "DeviceModule", "DeviceArray", "kernels", "sharded",
 ]

@@ -39,6 +39,7 @@ SIGNATURES = {
     "qs_add_spin_one_body": (c_int, [c_int, c_int, c_ptr, c_ptr, c_i64, c_i64, c_ptr]),
     "qs_spin_squared_two_body": (c_int, [c_ptr, c_ptr, c_i64, c_i64, c_i64, c_int, c_ptr]),
     "qs_tdho_coulomb_elements": (c_int, [c_ptr, c_i64, c_i64, c_i64, c_ptr]),
+    "qs_tdho_coulomb_elements_nm": (c_int, [c_ptr, c_ptr, c_i64, c_i64, c_i64, c_i64, c_ptr]),
     "qs_tuning_set": (c_int, [ctypes.c_char_p, c_i64]),
     "qs_probe_mfma_f64": (c_int, [c_ptr, c_i64, c_i64, c_ptr]),
     "qs_probe_stream_copy": (c_int, [c_ptr, c_ptr, c_i64, c_ptr]),

@@ -86,8 +86,10 @@ __device__ double tdho_element(const double* __restrict__ lf, const double* __re
     return element * exp(0.5 * prod_1);
 }
 
-__global__ __launch_bounds__(256) void tdho_coulomb_kernel(double* __restrict__ out, int l, int p_lo,
-                                                           int64_t total) {
+// nm_table: optional device table [2][l] of (n, m) per orbital (magnetic-field ordering,
+// two_dim_helper.py:284-301); nullptr = the shell order of two_dim_helper.py:132-166
+__global__ __launch_bounds__(256) void tdho_coulomb_kernel(double* __restrict__ out, const int* __restrict__ nm_table,
+                                                           int l, int p_lo, int64_t total) {
     __shared__ double s_lf[TD_MAXF];
     __shared__ double s_lgh[TD_MAXG];
     extern __shared__ int s_nm[];   // [2][l]
@@ -96,7 +98,10 @@ __global__ __launch_bounds__(256) void tdho_coulomb_kernel(double* __restrict__ 
         s_lf[0] = 0.0; s_lf[1] = 0.0;
         for (int n = 2; n < TD_MAXF; ++n) s_lf[n] = s_lf[n - 1] + log((double)n);   // coulomb_elements.py:95-102
     }
-    for (int p = threadIdx.x; p < l; p += blockDim.x) tdho_indices_nm(p, s_nm[p], s_nm[l + p]);
+    for (int p = threadIdx.x; p < l; p += blockDim.x) {
+        if (nm_table) { s_nm[p] = nm_table[p]; s_nm[l + p] = nm_table[l + p]; }
+        else tdho_indices_nm(p, s_nm[p], s_nm[l + p]);
+    }
     __syncthreads();
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     const int64_t l3 = (int64_t)l * l * l, l2 = (int64_t)l * l;
@@ -115,23 +120,37 @@ __global__ __launch_bounds__(256) void tdho_coulomb_kernel(double* __restrict__ 
 
 using namespace qs;
 
-extern "C" {
-
-int qs_tdho_coulomb_elements(void* out, int64_t l, int64_t p_lo, int64_t p_hi, void* stream) {
+static int launch_tdho(void* out, const int* nm_table, int64_t l, int shell, int64_t p_lo, int64_t p_hi,
+                       void* stream) {
     if (!out) return QS_ERR_NULL_POINTER;
     if (l <= 0 || l > TD_MAXL || p_lo < 0 || p_hi > l || p_lo >= p_hi) return QS_ERR_BAD_EXTENT;
     if (!aligned(out, 8)) return QS_ERR_MISALIGNED;
-    // the largest table index is G + 1 <= 4 * (2 n_max + |m|_max) + 1 and shells grow like sqrt(2 l)
-    int n_top, m_top;
-    tdho_indices_nm((int)l - 1, n_top, m_top);
-    const int shell = 2 * n_top + abs(m_top) + 1;
-    if (8 * shell + 8 >= TD_MAXF) return QS_ERR_BAD_EXTENT;
+    // the largest table index is G + 1 <= 4 * (2 n_max + |m|_max) + 1
+    if (shell < 1 || 8 * shell + 8 >= TD_MAXF) return QS_ERR_BAD_EXTENT;
     const int64_t total = (p_hi - p_lo) * l * l * l;
     const int64_t want = cdiv(total, 256);
     const unsigned grid = (unsigned)(want < 256 * 8 ? want : 256 * 8);
     hipLaunchKernelGGL(tdho_coulomb_kernel, dim3(grid), dim3(256), sizeof(int) * 2 * l, (hipStream_t)stream,
-                       (double*)out, (int)l, (int)p_lo, total);
+                       (double*)out, nm_table, (int)l, (int)p_lo, total);
     return launch_status("tdho_coulomb launch");
+}
+
+extern "C" {
+
+int qs_tdho_coulomb_elements(void* out, int64_t l, int64_t p_lo, int64_t p_hi, void* stream) {
+    if (l <= 0 || l > TD_MAXL) return QS_ERR_BAD_EXTENT;
+    // shells grow like sqrt(2 l): the last orbital sits in the highest one
+    int n_top, m_top;
+    tdho_indices_nm((int)l - 1, n_top, m_top);
+    return launch_tdho(out, nullptr, l, 2 * n_top + abs(m_top) + 1, p_lo, p_hi, stream);
+}
+
+int qs_tdho_coulomb_elements_nm(void* out, const void* nm_table, int64_t l, int64_t max_shell, int64_t p_lo,
+                                int64_t p_hi, void* stream) {
+    if (!nm_table) return QS_ERR_NULL_POINTER;
+    if (!aligned(nm_table, 4)) return QS_ERR_MISALIGNED;
+    if (max_shell < 1 || max_shell > 64) return QS_ERR_BAD_EXTENT;
+    return launch_tdho(out, (const int*)nm_table, l, (int)max_shell, p_lo, p_hi, stream);
 }
 
 }  // extern "C"

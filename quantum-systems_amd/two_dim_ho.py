@@ -12,10 +12,14 @@ The radial integrals, which the reference hands to sympy
 ``(a r)^|m| L_n^|m|(a^2 r^2) exp(-a^2 r^2 / 2)``, so with t = a^2 r^2 every
 integral is a finite sum of Gamma functions.
 
+``TwoDimHarmonicOscB``: the oscillator in a perpendicular magnetic field --
+orbitals ordered by their field-split energies (the reference builds a pandas
+frame for this, two_dim_helper.py:380-420; a ``lexsort`` here) and Coulomb
+elements generated for that orbital table.
+
 Not built: ``TwoDimSmoothDoubleWell`` (its constructor reads ``self.a`` before
 setting it and raises upstream, two_dim_ho.py:190-210; the element generator is
-here as a function) and ``TwoDimHarmonicOscB`` (pandas-based level table and a
-different Coulomb routine).
+here as a function).
 """
 
 import math
@@ -64,21 +68,50 @@ def get_one_body_elements(num_orbitals):
     return h
 
 
-def get_coulomb_elements(num_orbitals, p_lo=0, p_hi=None, device=None):
+def get_coulomb_elements(num_orbitals, p_lo=0, p_hi=None, device=None, nm=None):
     """Coulomb elements ``u[p, q, r, s]`` (omega = 1) as a device tensor,
-    rows ``p_lo:p_hi`` (two_dim_helper.py:185-268; generated on the GPU)."""
+    rows ``p_lo:p_hi`` (two_dim_helper.py:185-268; generated on the GPU).
+    ``nm``: optional list of (n, m) per orbital replacing the shell order
+    (``get_coulomb_elements_B``, two_dim_helper.py:284-301)."""
     if not torch.cuda.is_available():
         raise RuntimeError("the Coulomb-element generator runs on the GPU only")
     p_hi = num_orbitals if p_hi is None else p_hi
     device = torch.device("cuda", torch.cuda.current_device()) if device is None else device
     out = torch.empty((p_hi - p_lo,) + (num_orbitals,) * 3, dtype=torch.float64, device=device)
+    stream = torch.cuda.current_stream().cuda_stream
+    if nm is None:
+        _lib.check(_lib.load().qs_tdho_coulomb_elements(out.data_ptr(), num_orbitals, p_lo, p_hi, stream),
+                   "qs_tdho_coulomb_elements")
+        return out
+    nm = numpy.asarray(nm, dtype=numpy.int32)
+    if nm.shape != (num_orbitals, 2):
+        raise ValueError("nm must list (n, m) for every orbital")
+    table = torch.from_numpy(numpy.ascontiguousarray(nm.T)).to(device)        # n of all, then m of all
+    max_shell = int((2 * nm[:, 0] + abs(nm[:, 1]) + 1).max())
     _lib.check(
-        _lib.load().qs_tdho_coulomb_elements(
-            out.data_ptr(), num_orbitals, p_lo, p_hi, torch.cuda.current_stream().cuda_stream
-        ),
-        "qs_tdho_coulomb_elements",
+        _lib.load().qs_tdho_coulomb_elements_nm(out.data_ptr(), table.data_ptr(), num_orbitals, max_shell,
+                                                p_lo, p_hi, stream),
+        "qs_tdho_coulomb_elements_nm",
     )
     return out
+
+
+def get_shell_energy_B(n, m, omega_c=0, omega=1):
+    """Fock-Darwin level in a perpendicular field (two_dim_helper.py:271-272)."""
+    return omega * (2 * n + abs(m) + 1) - (omega_c * m) / 2
+
+
+def construct_level_table(n_array, m_array, omega_c=0, omega=1):
+    """Orbitals (n, m) over ``n_array x m_array`` ordered by their energy in the
+    field, ties by m -- the rows of the reference's pandas frame
+    (two_dim_helper.py:380-420; its degeneracy columns and the capping of the
+    frame do not enter any matrix element).  Returns ``(nm, E)``: an (N, 2) int
+    array and the N energies."""
+    n, m = numpy.meshgrid(numpy.asarray(n_array, dtype=float), numpy.asarray(m_array, dtype=float), indexing="ij")
+    n, m = n.ravel(), m.ravel()
+    E = get_shell_energy_B(n, m, omega_c=omega_c, omega=omega)
+    order = numpy.lexsort((m, E))                      # by E, then by m; stable
+    return numpy.stack([n[order], m[order]], axis=1).astype(int), E[order]
 
 
 def bohr_radius(mass, omega):
@@ -253,3 +286,33 @@ class TwoDimensionalDoubleWell(TwoDimensionalHarmonicOscillator):
             self.np,
         )
         self.change_module(self.np)
+
+
+class TwoDimHarmonicOscB(TwoDimensionalHarmonicOscillator):
+    """The 2-D oscillator in a homogeneous perpendicular magnetic field of
+    cyclotron frequency ``omega_c`` (two_dim_ho.py:213-276): effective frequency
+    ``sqrt(omega^2 + omega_c^2 / 4)``, orbitals ordered by their energy in the
+    field, ``h = diag(E)``, Coulomb elements for that orbital table
+    (``qs_tdho_coulomb_elements_nm``).  Everything is cast to complex128."""
+
+    def __init__(self, *args, omega_c=0, **kwargs):
+        self.omega_c = omega_c
+        super().__init__(*args, **kwargs)
+
+    def setup_basis(self):
+        np = self.np
+        self.omega = numpy.sqrt(self.omega**2 + self.omega_c**2 / 4)
+        l = self.l
+        self.level_nm, self.level_energy = construct_level_table(
+            numpy.arange(l), numpy.arange(-l - 5, l + 6), omega_c=self.omega_c, omega=self.omega)
+        self._h = convert(numpy.diag(self.level_energy[:l]), np)
+        self._s = convert(numpy.eye(l), np)
+        self._u = convert(numpy.sqrt(self.omega) * get_coulomb_elements(l, nm=self.level_nm[:l]), np)
+        self.setup_spf()
+        self.construct_position_integrals()
+        self.cast_to_complex()
+        self.change_module(np)
+
+    def get_indices_nm(self, p):
+        n, m = self.level_nm[p]
+        return int(n), int(m)

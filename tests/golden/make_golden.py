@@ -411,6 +411,21 @@ def case_tdho_one_body():
         sums.append(np.abs(tab).sum())
     out.update(spf_files_pts=pts, spf_files_val=np.array(vals), spf_files_abs_sum=np.array(sums),
                spf_files_shape=np.array(tab.shape))
+    # magnetic-field dot: the reference's level table (pandas frame) for a few parameter sets and its
+    # regression files tests/dat/tdhob_{h,u,dipole_moment}.npy (GeneralOrbitalSystem(2, TwoDimHarmonicOscB(
+    # 10, 5, 201, omega_c=0.5)), tests/test_two_dim_ho_b_field.py:11-40)
+    for tag, (l, wc, w0) in {"a": (10, 0.5, 1.0), "b": (6, 0.0, 1.0), "c": (12, 1.3, 0.7)}.items():
+        w = np.sqrt(w0**2 + wc**2 / 4)
+        df = hlp.construct_dataframe(np.arange(l), np.arange(-l - 5, l + 6), omega_c=wc, omega=w)
+        out[f"levels_{tag}_params"] = np.array([l, wc, w0])
+        out[f"levels_{tag}_nm"] = df[["n", "m"]].values.astype(int)
+        out[f"levels_{tag}_E"] = df["E"].values
+    ub = np.load(os.path.join(dat, "tdhob_u.npy"))
+    bi = rng.integers(0, ub.shape[0], size=(4000, 4))
+    out.update(tdhob_h=np.load(os.path.join(dat, "tdhob_h.npy")),
+               tdhob_dipole_moment=np.load(os.path.join(dat, "tdhob_dipole_moment.npy")),
+               tdhob_u_idx=bi, tdhob_u_val=ub[tuple(bi.T)], tdhob_u_abs_sum=np.abs(ub).sum(),
+               tdhob_u_shape=np.array(ub.shape))
     save("tdho_one_body", **out)
 
 

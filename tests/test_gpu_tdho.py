@@ -153,3 +153,39 @@ def test_change_of_basis_like_reference():
     # and the rotated double-well h is diagonal with the double-well energies (spin doubled)
     eps = np.linalg.eigvalsh(h_dw)
     np.testing.assert_allclose(np.asarray(tddw.h), np.diag(np.repeat(eps, 2)), atol=1e-9)
+
+
+def test_tdhob_like_reference():
+    # tests/test_two_dim_ho_b_field.py:11-40 against the reference's own regression files
+    # (signed comparison, atol 1e-10; u as 4000 sampled entries + absolute sum)
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "tdho_one_body.npz"))
+    tdhob = qsa.GeneralOrbitalSystem(2, qsa.TwoDimHarmonicOscB(10, 5, 201, omega_c=0.5))
+    H = qsa.array_module.to_host
+    np.testing.assert_allclose(g["tdhob_dipole_moment"], np.asarray(H(tdhob.position)), atol=1e-10)
+    np.testing.assert_allclose(g["tdhob_h"], np.asarray(H(tdhob.h)), atol=1e-10)
+    u = np.asarray(H(tdhob.u))
+    assert u.shape == tuple(g["tdhob_u_shape"]) and u.dtype == np.complex128
+    bi = g["tdhob_u_idx"]
+    np.testing.assert_allclose(g["tdhob_u_val"], u[tuple(bi.T)], atol=1e-10)
+    np.testing.assert_allclose(g["tdhob_u_abs_sum"], np.abs(u).sum(), rtol=1e-9)
+    # level table of the basis = the reference's pandas frame
+    np.testing.assert_array_equal(tdhob._basis_set.level_nm[: len(g["levels_a_nm"])], g["levels_a_nm"])
+
+
+def test_two_body_elements_compare_like_reference():
+    # tests/test_two_dim_ho_b_field.py:43-75: without a field the two generators agree
+    a = qsa.GeneralOrbitalSystem(2, qsa.TwoDimensionalHarmonicOscillator(6, 5, 41, mass=1, omega=1))
+    b = qsa.GeneralOrbitalSystem(2, qsa.TwoDimHarmonicOscB(6, 5, 41, mass=1, omega=1, omega_c=0))
+    np.testing.assert_allclose(np.asarray(a.u), np.asarray(b.u), atol=1e-8)
+
+
+def test_coulomb_elements_with_orbital_table_vs_oracle(td):
+    # table-driven entry point against the C oracle, element by element, for a field-ordered table
+    nm, _ = co.level_table(np.arange(8), np.arange(-13, 14), omega_c=0.9, omega=np.sqrt(1 + 0.81 / 4))
+    l = 12
+    u = td.get_coulomb_elements(l, nm=nm[:l]).cpu().numpy()
+    rng = np.random.default_rng(2)
+    for p, q, r, s in rng.integers(0, l, size=(400, 4)):
+        assert abs(u[p, q, r, s] - co.coulomb_element_nm(nm, p, q, r, s)) <= 1e-11
+    with pytest.raises(ValueError):
+        td.get_coulomb_elements(l, nm=nm[:5])

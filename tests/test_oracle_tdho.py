@@ -87,3 +87,25 @@ def test_spf_tables_match_the_reference_files(golden):
     for p in range(15):
         np.testing.assert_allclose(spf[p][tuple(pts.T)], g["spf_files_val"][p], rtol=1e-7, atol=1e-12)
         np.testing.assert_allclose(np.abs(spf[p]).sum(), g["spf_files_abs_sum"][p], rtol=1e-9)
+
+
+def test_magnetic_field_level_table_and_elements(golden):
+    g = golden("tdho_one_body")
+    for tag in "abc":
+        l, wc, w0 = g[f"levels_{tag}_params"]
+        l = int(l)
+        w = np.sqrt(w0**2 + wc**2 / 4)
+        nm, E = co.level_table(np.arange(l), np.arange(-l - 5, l + 6), omega_c=wc, omega=w)
+        k = len(g[f"levels_{tag}_E"])
+        np.testing.assert_array_equal(nm[:k], g[f"levels_{tag}_nm"])
+        np.testing.assert_allclose(E[:k], g[f"levels_{tag}_E"], rtol=0, atol=0)
+    # the reference's regression file of the spin-doubled, anti-symmetrised u (sampled): element by element
+    l, wc, w0 = g["levels_a_params"]
+    w = np.sqrt(w0**2 + wc**2 / 4)
+    nm = g["levels_a_nm"]
+    for (P, Q, R, S), ref in list(zip(g["tdhob_u_idx"], g["tdhob_u_val"]))[:600]:
+        p, q, r, s = P // 2, Q // 2, R // 2, S // 2
+        direct = co.coulomb_element_nm(nm, p, q, r, s) if (P % 2 == R % 2 and Q % 2 == S % 2) else 0.0
+        exchange = co.coulomb_element_nm(nm, p, q, s, r) if (P % 2 == S % 2 and Q % 2 == R % 2) else 0.0
+        assert abs(np.sqrt(w) * (direct - exchange) - ref) <= 1e-10
+    np.testing.assert_allclose(np.diag(g["tdhob_h"]).real, np.repeat(g["levels_a_E"][:10], 2), atol=1e-12)
