@@ -47,9 +47,13 @@ static inline char* at(void* base, int64_t elems, size_t es) { return (char*)bas
 static int contract_dcb(int dtype, const void* u, const void* C, const void* CT, const void* Ct,
                         void* T1, void* T2, void* T3, int64_t rows, int64_t L, int64_t M,
                         hipStream_t s) {
-    int rc = gemm(dtype, u, C, T1, rows * L * L, M, L, L, M, M, 1, 0, 0, 0, s);
-    if (rc) return rc;
-    rc = gemm(dtype, CT, T1, T2, M, M, L, L, M, M, rows * L, 0, L * M, M * M, s);
+    // small bases: d and c in one pass over the tensor (each slab u[a, b] is contiguous)
+    int rc = slab_pair_try(dtype, u, CT, C, T2, rows * L, L, M, s);
+    if (rc == 1) {
+        rc = gemm(dtype, u, C, T1, rows * L * L, M, L, L, M, M, 1, 0, 0, 0, s);
+        if (rc) return rc;
+        rc = gemm(dtype, CT, T1, T2, M, M, L, L, M, M, rows * L, 0, L * M, M * M, s);
+    }
     if (rc) return rc;
     return gemm(dtype, Ct, T2, T3, M, M * M, L, L, M * M, M * M, rows, 0, L * M * M, M * M * M, s);
 }
@@ -86,6 +90,7 @@ int qs_tuning_set(const char* key, int64_t value) {
     if (!strcmp(key, "gemm_fast")) { g_gemm_fast = (int)value; return QS_OK; }
     if (!strcmp(key, "gemm_skinny")) { g_gemm_skinny = (int)value; return QS_OK; }
     if (!strcmp(key, "gemm_stream")) { g_gemm_stream = (int)value; return QS_OK; }
+    if (!strcmp(key, "slab_pair")) { g_slab_pair = (int)value; return QS_OK; }
     if (!strcmp(key, "gemm_fast_persist")) { g_gemm_fast_persist = (int)value; return QS_OK; }
     if (!strcmp(key, "gemm_fast_shape")) { g_gemm_fast_shape = (int)value; return QS_OK; }
     return QS_ERR_BAD_EXTENT;

@@ -494,6 +494,50 @@ def test_stream_product_keeps_non_finite_values_in_their_columns(K):
     np.testing.assert_allclose(got[ok], ref[ok], rtol=1e-12, atol=1e-12)
 
 
+# ------------------------------------------- fused (d, c) pass for small bases (qs_slab_pair.hip)
+
+
+@pytest.mark.parametrize("L,M", [(16, 16), (20, 33), (32, 32), (33, 17), (48, 64), (55, 55), (64, 64), (64, 5), (41, 60)])
+def test_fused_dc_pass_equals_two_products(K, L, M):
+    # d and c in one pass (Y = X.C stays in the MFMA accumulators): same chains of fused multiply-adds
+    # as the two separate products, so the whole transform is bit-identical with and without it
+    rng = np.random.default_rng(L * 100 + M)
+    u = rng.standard_normal((L,) * 4)
+    C = rng.standard_normal((L, M)) / np.sqrt(L)
+    Ct = rng.standard_normal((M, L)) / np.sqrt(L)
+    ref = orc.transform_two_body(u, C, Ct)
+    try:
+        K.tuning_set("slab_pair", 0)
+        plain = host(K.transform_two_body(dev(u), dev(C), dev(Ct)))
+        K.tuning_set("slab_pair", 1)
+        fused = host(K.transform_two_body(dev(u), dev(C), dev(Ct)))
+        part = host(K.transform_two_body_partial(dev(u[3:9]), dev(C), dev(Ct)))
+    finally:
+        K.tuning_set("slab_pair", 1)
+    assert relerr(fused, ref) <= 1e-13
+    assert np.array_equal(fused, plain)
+    np.testing.assert_allclose(part, orc.transform_two_body_dcb(u[3:9], C, Ct), rtol=1e-12, atol=1e-13)
+
+
+def test_fused_dc_pass_keeps_non_finite_values_in_their_slabs(K):
+    # K tails of a slab alias its next row and the row tail of a slab aliases the NEXT slab: a NaN / Inf
+    # at the very start of slab (4, 0) / (6, 0) must not reach slab (3, L-1) / (5, L-1).  (Checked per
+    # leading index a: the b contraction that follows mixes the slabs of one a, as it does in NumPy.)
+    rng = np.random.default_rng(6)
+    L = 21
+    u = rng.standard_normal((L,) * 4)
+    C = rng.standard_normal((L, L))
+    u[4, 0, 0, 0] = np.nan
+    u[6, 0, 0, 1] = np.inf
+    clean = np.delete(u, [4, 6], axis=0)
+    ref = orc.transform_two_body_dcb(clean, C, C.T.copy())
+    got = host(K.transform_two_body_partial(dev(u), dev(C), dev(C.T.copy())))
+    assert not np.isfinite(got[4]).any() and not np.isfinite(got[6]).any()
+    rest = np.delete(got, [4, 6], axis=0)
+    assert np.isfinite(rest).all()
+    np.testing.assert_allclose(rest, ref, rtol=1e-11, atol=1e-11)
+
+
 def test_replicated_layout_matches_full_transform(K):
     # sharded.transform_two_body_replicated on one GPU, every rank's slab (uses the skinny product)
     from quantum_systems_amd import sharded

@@ -33,12 +33,15 @@ def run(l, dt):
     res = []
     ref = None
     variants = [("general", 2, 0), ("edge auto", 3, 0)] + [(f"edge s{s}", 3, s) for s in (1, 2, 3, 4)]
+    if os.environ.get("QS_SWEEP") == "slab":
+        variants = [("two products", 1, 0, 1, 0), ("fused d+c", 1, 0, 1, 1)]
     if os.environ.get("QS_SWEEP") == "stream":
         variants = [("tiled", 1, 0, 0), ("stream", 1, 0, 1), ("stream no-split", 1, 0, 2)]
     for label, fast, shape, *rest in variants:
         if dt.is_complex and shape == 4:
             continue
         K.tuning_set("gemm_stream", rest[0] if rest else 0)
+        K.tuning_set("slab_pair", rest[1] if len(rest) > 1 else 1)
         K.tuning_set("gemm_fast", fast)
         K.tuning_set("gemm_fast_shape", shape)
         reps = 20 if l <= 64 else 5
