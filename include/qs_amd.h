@@ -201,7 +201,8 @@ int qs_tdho_coulomb_elements_nm(void* out, const void* nm_table, int64_t l,
  *     "gemm_skinny" (0 = never use the streaming short-and-wide kernel),
  *     "gemm_stream" (0 = never use the small-coefficient streaming kernel,
  *     2 = never split the rows of A over two waves), "slab_pair" (0 = never fuse
- *     the d and c contractions of a small-basis transform into one pass).
+ *     the d and c contractions of a small-basis transform into one pass, 2 = one
+ *     wave per slab always).
  *   qs_probe_mfma_f64: register-resident fp64 MFMA loop, `blocks` workgroups
  *     of 4 waves, each wave issuing iters*8 v_mfma_f64_16x16x4_f64
  *     (flops = blocks*4*iters*8*2048); `sink` is a device scratch of

@@ -187,10 +187,150 @@ void slab_pair_kernel(const SlabArgs g) {
     }
 }
 
-int g_slab_pair = 1;   // tuning knob: 0 disables the fused (d, c) pass
-
+// Two waves per slab: each wave takes half of the COLUMN tiles of B, Y and Z (the two products are
+// column-wise independent), reads all of X itself (the second reader hits L1/L2) and keeps only a
+// four-k-step ring of X fragments -- about 200 registers, so two waves share a SIMD and one wave's
+// waits (loads at a slab's start, the stores at its end) are covered by the other's MFMAs.  The ring
+// runs across slab boundaries (k-step kk + 4 of this slab, or kk + 4 - KS of the wave's next one,
+// always lands in slot kk & 3 because KS is a multiple of 4).
 template <int TL, int TM>
-static int launch_slab_pair(const SlabArgs& g, hipStream_t stream) {
+__global__ __launch_bounds__(256, 2)
+void slab_pair_split_kernel(const SlabArgs g) {
+    static_assert(TM % 2 == 0, "column tiles are split between two waves");
+    constexpr int KS = 4 * TL, TH = TM / 2, R = 4;
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    double* bfrag = lds;                          // [KS][TM][64]
+    double* afrag = lds + KS * TM * 64;           // [TM][KS][64]
+    const int L = g.L, M = g.M;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int c16 = lane & 15, g4 = lane >> 4;
+    const int half = wave & 1, j0 = half * TH;
+
+    for (int f = tid; f < KS * TM * 64; f += 256) {
+        const int ln = f & 63, j = (f >> 6) % TM, kk = (f >> 6) / TM;
+        const int k = 4 * kk + (ln >> 4), col = 16 * j + (ln & 15);
+        bfrag[f] = (k < L && col < M) ? g.B[(int64_t)k * M + col] : 0.0;
+    }
+    for (int f = tid; f < TM * KS * 64; f += 256) {
+        const int ln = f & 63, kk = (f >> 6) % KS, i = (f >> 6) / KS;
+        const int row = 16 * i + (ln & 15), k = 4 * kk + (ln >> 4);
+        afrag[f] = (row < M && k < L) ? g.A[(int64_t)row * L + k] : 0.0;
+    }
+    __syncthreads();
+
+    const unsigned w = blockIdx.x * 2 + (wave >> 1), W = gridDim.x * 2;
+    if (w >= g.nslabs) return;
+
+    const unsigned x_slab = (unsigned)(L * L * 8), z_slab = (unsigned)(M * M * 8);
+    auto rsrc = [&](const double* base, unsigned slab, unsigned stride, unsigned room) __attribute__((always_inline)) {
+        const uint64_t p = reinterpret_cast<uint64_t>(base) + (uint64_t)slab * stride;
+        const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)p);
+        const uint32_t hi = __builtin_amdgcn_readfirstlane((uint32_t)(p >> 32));
+        return __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void*>(((uint64_t)hi << 32) | lo), (short)0,
+                                                 (int)room, 0x00020000);
+    };
+    unsigned x_off[TL];
+#pragma unroll
+    for (int i = 0; i < TL; ++i) x_off[i] = (unsigned)((16 * i + c16) * L + g4) * 8u;
+    auto load_x = [&](auto rs, int i, int kk) __attribute__((always_inline)) {
+        return __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(rs, (int)(x_off[i] + kk * 32), 0, 0));
+    };
+
+    double xr[TL][R];
+    {
+        const auto rs = rsrc(g.X, w, x_slab, x_slab);
+#pragma unroll
+        for (int kk = 0; kk < R; ++kk)
+#pragma unroll
+            for (int i = 0; i < TL; ++i) xr[i][kk] = load_x(rs, i, kk);
+    }
+
+    for (unsigned s = w; s < g.nslabs; s += W) {
+        const unsigned nxt = s + W < g.nslabs ? s + W : s;
+        const auto rs_cur = rsrc(g.X, s, x_slab, x_slab);
+        const auto rs_next = rsrc(g.X, nxt, x_slab, x_slab);
+
+        f64x4 Y[TL][TH];
+#pragma unroll
+        for (int i = 0; i < TL; ++i)
+#pragma unroll
+            for (int j = 0; j < TH; ++j) Y[i][j] = f64x4{0.0, 0.0, 0.0, 0.0};
+        double bf[2][TH];
+#pragma unroll
+        for (int j = 0; j < TH; ++j) bf[0][j] = bfrag[(j0 + j) * 64 + lane];
+#pragma unroll
+        for (int kk = 0; kk < KS; ++kk) {
+            __builtin_amdgcn_sched_barrier(0);
+            if (kk + 1 < KS) {
+#pragma unroll
+                for (int j = 0; j < TH; ++j) bf[(kk + 1) & 1][j] = bfrag[((kk + 1) * TM + j0 + j) * 64 + lane];
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            if (4 * kk < L) {                          // (a k-step wholly in the padding multiplies nothing)
+                const bool k_ok = 4 * kk + g4 < L;
+#pragma unroll
+                for (int i = 0; i < TL; ++i) {
+                    const double xa = k_ok ? xr[i][kk & 3] : 0.0;
+#pragma unroll
+                    for (int j = 0; j < TH; ++j)
+                        Y[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(xa, bf[kk & 1][j], Y[i][j], 0, 0, 0);
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            // refill the slot: four k-steps ahead, in this slab or at the start of the wave's next one
+#pragma unroll
+            for (int i = 0; i < TL; ++i)
+                xr[i][kk & 3] = kk + R < KS ? load_x(rs_cur, i, kk + R) : load_x(rs_next, i, kk + R - KS);
+        }
+
+        f64x4 Zt[TM][TH];
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TH; ++j) Zt[i][j] = f64x4{0.0, 0.0, 0.0, 0.0};
+        double af[2][TM];
+#pragma unroll
+        for (int i = 0; i < TM; ++i) af[0][i] = afrag[(i * KS) * 64 + lane];
+#pragma unroll
+        for (int kk = 0; kk < KS; ++kk) {
+            __builtin_amdgcn_sched_barrier(0);
+            if (kk + 1 < KS) {
+#pragma unroll
+                for (int i = 0; i < TM; ++i) af[(kk + 1) & 1][i] = afrag[(i * KS + kk + 1) * 64 + lane];
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            if (4 * kk < L) {
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TH; ++j)
+                        Zt[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[kk & 1][i], Y[kk >> 2][j][kk & 3], Zt[i][j], 0, 0, 0);
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+
+        const auto rs_z = rsrc(g.Z, s, z_slab, z_slab);
+#pragma unroll
+        for (int j = 0; j < TH; ++j) {
+            const int col = 16 * (j0 + j) + c16;
+            const unsigned o0 = col < M ? (unsigned)(g4 * M + col) * 8u : 0x80000000u;
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const unsigned o = o0 + (unsigned)((16 * i + 4 * r) * M) * 8u;
+                    const double z = Zt[i][j][r];
+                    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, z), rs_z, (int)o, 0, 0);
+                }
+            }
+        }
+    }
+}
+
+int g_slab_pair = 1;   // tuning knob: 0 disables the fused (d, c) pass, 2 = one wave per slab always
+
+static int device_cus() {
     static int n_cu = 0;
     if (n_cu == 0) {
         int dev = 0;
@@ -202,11 +342,25 @@ static int launch_slab_pair(const SlabArgs& g, hipStream_t stream) {
             n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
         }
     }
+    return n_cu;
+}
+
+template <int TL, int TM>
+static int launch_slab_pair(const SlabArgs& g, hipStream_t stream) {
+    const int n_cu = device_cus();
+    const size_t lds = sizeof(double) * 2 * (4 * TL) * TM * 64;
+    if constexpr (TM % 2 == 0) {
+        if (g_slab_pair != 2) {
+            // two waves per slab, two workgroups (four slabs in flight) per CU
+            int64_t wgs = cdiv(g.nslabs, 2);
+            if (wgs > 2 * (int64_t)n_cu) wgs = 2 * (int64_t)n_cu;
+            hipLaunchKernelGGL((slab_pair_split_kernel<TL, TM>), dim3((unsigned)wgs), dim3(256), lds, stream, g);
+            return launch_status("slab_pair_split launch");
+        }
+    }
     int64_t wgs = cdiv(g.nslabs, 4);
     if (wgs > n_cu) wgs = n_cu;                       // one wave per SIMD, persistent
-    const size_t lds = sizeof(double) * 2 * (4 * TL) * TM * 64;
-    auto kern = slab_pair_kernel<TL, TM>;
-    hipLaunchKernelGGL(kern, dim3((unsigned)wgs), dim3(256), lds, stream, g);
+    hipLaunchKernelGGL((slab_pair_kernel<TL, TM>), dim3((unsigned)wgs), dim3(256), lds, stream, g);
     return launch_status("slab_pair launch");
 }
 

@@ -509,13 +509,15 @@ def test_fused_dc_pass_equals_two_products(K, L, M):
     try:
         K.tuning_set("slab_pair", 0)
         plain = host(K.transform_two_body(dev(u), dev(C), dev(Ct)))
-        K.tuning_set("slab_pair", 1)
+        K.tuning_set("slab_pair", 2)          # one wave per slab
+        fused1 = host(K.transform_two_body(dev(u), dev(C), dev(Ct)))
+        K.tuning_set("slab_pair", 1)          # automatic: two waves per slab when M spans an even number of tiles
         fused = host(K.transform_two_body(dev(u), dev(C), dev(Ct)))
         part = host(K.transform_two_body_partial(dev(u[3:9]), dev(C), dev(Ct)))
     finally:
         K.tuning_set("slab_pair", 1)
     assert relerr(fused, ref) <= 1e-13
-    assert np.array_equal(fused, plain)
+    assert np.array_equal(fused, plain) and np.array_equal(fused1, plain)
     np.testing.assert_allclose(part, orc.transform_two_body_dcb(u[3:9], C, Ct), rtol=1e-12, atol=1e-13)
 
 

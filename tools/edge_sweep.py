@@ -34,7 +34,7 @@ def run(l, dt):
     ref = None
     variants = [("general", 2, 0), ("edge auto", 3, 0)] + [(f"edge s{s}", 3, s) for s in (1, 2, 3, 4)]
     if os.environ.get("QS_SWEEP") == "slab":
-        variants = [("two products", 1, 0, 1, 0), ("fused d+c", 1, 0, 1, 1)]
+        variants = [("two products", 1, 0, 1, 0), ("fused 1 wave/slab", 1, 0, 1, 2), ("fused 2 waves/slab", 1, 0, 1, 1)]
     if os.environ.get("QS_SWEEP") == "stream":
         variants = [("tiled", 1, 0, 0), ("stream", 1, 0, 1), ("stream no-split", 1, 0, 2)]
     for label, fast, shape, *rest in variants:
