@@ -26,11 +26,19 @@ def test_full_size_elementwise_parity_vs_numpy():
     from quantum_systems_amd import kernels as K
 
     l = int(os.environ.get("QS_FULL_SIZE_L", "256"))
+    cplx = os.environ.get("QS_FULL_SIZE_DTYPE", "f64") == "c128"
+    dt = torch.complex128 if cplx else torch.float64
     g = torch.Generator(device="cuda:0").manual_seed(99)
-    u = torch.empty((l, l, l, l), dtype=torch.float64, device="cuda:0")
+    u = torch.empty((l, l, l, l), dtype=dt, device="cuda:0")
     for lo in range(0, l, 8):
-        u[lo:lo + 8] = torch.rand((min(8, l - lo), l, l, l), dtype=torch.float64, device="cuda:0", generator=g)
-    C, _ = torch.linalg.qr(torch.randn(l, l, dtype=torch.float64, device="cuda:0", generator=g))
+        blk = torch.rand((min(8, l - lo), l, l, l), dtype=torch.float64, device="cuda:0", generator=g)
+        if cplx:
+            blk = torch.complex(blk, torch.rand(blk.shape, dtype=torch.float64, device="cuda:0", generator=g))
+        u[lo:lo + 8] = blk
+    a = torch.randn(l, l, dtype=torch.float64, device="cuda:0", generator=g)
+    if cplx:
+        a = torch.complex(a, torch.randn(l, l, dtype=torch.float64, device="cuda:0", generator=g))
+    C, _ = torch.linalg.qr(a)
     t0 = time.perf_counter()
     out = K.transform_two_body(u, C)
     torch.cuda.synchronize()
@@ -54,6 +62,6 @@ def test_full_size_elementwise_parity_vs_numpy():
         scale = max(scale, float(np.abs(ref[p]).max()))
     rel = worst / scale
     print(f"\nelements that differ at all: {differing} of {l**4}")
-    print(f"\nfull-size parity l={l}: max|diff| = {worst:.3e}, max|ref| = {scale:.3e}, relative {rel:.3e}; "
+    print(f"\nfull-size parity l={l} {'complex128' if cplx else 'fp64'}: max|diff| = {worst:.3e}, max|ref| = {scale:.3e}, relative {rel:.3e}; "
           f"GPU {t_gpu:.2f} s (first call), NumPy {t_cpu:.1f} s")
     assert rel <= 1e-10
