@@ -48,7 +48,7 @@ static int contract_dcb(int dtype, const void* u, const void* C, const void* CT,
                         void* T1, void* T2, void* T3, int64_t rows, int64_t L, int64_t M,
                         hipStream_t s) {
     // small bases: d and c in one pass over the tensor (each slab u[a, b] is contiguous)
-    int rc = slab_pair_try(dtype, u, CT, C, T2, rows * L, L, M, s);
+    int rc = slab_pair_try(dtype, u, C, T2, rows * L, L, M, s);
     if (rc == 1) {
         rc = gemm(dtype, u, C, T1, rows * L * L, M, L, L, M, M, 1, 0, 0, 0, s);
         if (rc) return rc;

@@ -52,9 +52,9 @@ int gemm_stream_try(int dtype, const double* A, const double* B, double* C, int6
                     int64_t k, int64_t lda, int64_t ldb, int64_t ldc, int64_t batch, int64_t sa,
                     int64_t sb, int64_t sc, int accumulate, hipStream_t stream);
 
-// Fused pair of contractions on contiguous L x L slabs, L, M <= 64 (qs_slab_pair.hip): Z[s] = A.X[s].B.
-int slab_pair_try(int dtype, const void* X, const void* A, const void* B, void* Z, int64_t nslabs, int64_t L,
-                  int64_t M, hipStream_t stream);
+// Fused pair of contractions on contiguous L x L slabs, L, M <= 64 (qs_slab_pair.hip): Z[s] = B^T.X[s].B.
+int slab_pair_try(int dtype, const void* X, const void* B, void* Z, int64_t nslabs, int64_t L, int64_t M,
+                  hipStream_t stream);
 
 // Short-and-wide streaming product (qs_gemm_skinny.hip): same return convention.
 int gemm_skinny_try(int dtype, const double* A, const double* B, double* C, int64_t m, int64_t n,

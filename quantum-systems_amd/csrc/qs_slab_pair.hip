@@ -1,9 +1,9 @@
-// Two contractions in one pass for small bases:  Z[s] = A . X[s] . B  for a stack of
-// L x L slabs X[s] (contiguous), A (M x L), B (L x M), L, M <= 64, fp64.
+// Two contractions in one pass for small bases:  Z[s] = B^T . X[s] . B  for a stack of
+// L x L slabs X[s] (contiguous), B (L x M), L, M <= 64, fp64.
 //
 // This is the pair (d, c) of the four-index transform,
-//     T2[ab][r, s] = sum_c CT[r, c] ( sum_d u[ab][c, d] C[d, s] ),
-// with X[s] = u[a, b, :, :], B = C, A = C^T: the slab u[a, b] is contiguous in
+//     T2[ab][r, s] = sum_c C[c, r] ( sum_d u[ab][c, d] C[d, s] ),
+// with X[s] = u[a, b, :, :] and B = C (the c contraction uses C^T, not the bra): the slab u[a, b] is contiguous in
 // memory, so the pair reads the tensor once and writes it once instead of twice
 // each (basis_set.py:341-344).  Below l ~ 100 the transform is bound by its passes
 // over the tensor and by per-tile overhead, not by the matrix pipe
@@ -14,9 +14,11 @@
 // tile, column lane&15) IS its B-operand layout for k = that row -- register r of
 // row tile i of Y = X.B is the B fragment of k-step 4i + r of A.Y.  So Y never
 // leaves the accumulators: no LDS round trip, no shuffle.
-//   * A and B live in LDS once per workgroup as ready-made MFMA fragments
-//     (fragment-major: one ds_read_b64 per fragment, lane-linear, conflict-free),
-//     zero-padded to whole tiles;
+//   * B lives in LDS once per workgroup as ready-made MFMA fragments (fragment-major:
+//     one ds_read_b64 per fragment, lane-linear, conflict-free), zero-padded to whole
+//     tiles.  ONE table serves both products: the A-operand fragment of B^T for row
+//     tile i and k-step kk (lane -> B^T[16i + c][4kk + g] = B[4kk + g][16i + c]) is
+//     the B-operand fragment of B for k-step kk and column tile i;
 //   * X fragments come straight from global memory (the A-operand layout wants
 //     X[row][k] per lane: 8-byte loads, 16 rows x 32 bytes per instruction, the
 //     rest of every line is picked up by the following k-steps from L1/L2); the
@@ -38,7 +40,6 @@ typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 
 struct SlabArgs {
     const double* X;
-    const double* A;   // (M, L) row-major
     const double* B;   // (L, M) row-major
     double* Z;
     int L, M;
@@ -52,7 +53,6 @@ void slab_pair_kernel(const SlabArgs g) {
     constexpr int KS = 4 * TL;                    // k-steps of either product (K = L padded to 16 TL)
     extern __shared__ __attribute__((aligned(16))) double lds[];
     double* bfrag = lds;                          // [KS][TM][64]:  B[4kk + g4][16j + c16]
-    double* afrag = lds + KS * TM * 64;           // [TM][KS][64]:  A[16i + c16][4kk + g4]
     const int L = g.L, M = g.M;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -62,11 +62,6 @@ void slab_pair_kernel(const SlabArgs g) {
         const int ln = f & 63, j = (f >> 6) % TM, kk = (f >> 6) / TM;
         const int k = 4 * kk + (ln >> 4), col = 16 * j + (ln & 15);
         bfrag[f] = (k < L && col < M) ? g.B[(int64_t)k * M + col] : 0.0;
-    }
-    for (int f = tid; f < TM * KS * 64; f += 256) {
-        const int ln = f & 63, kk = (f >> 6) % KS, i = (f >> 6) / KS;
-        const int row = 16 * i + (ln & 15), k = 4 * kk + (ln >> 4);
-        afrag[f] = (row < M && k < L) ? g.A[(int64_t)row * L + k] : 0.0;
     }
     __syncthreads();
 
@@ -147,14 +142,14 @@ void slab_pair_kernel(const SlabArgs g) {
             for (int j = 0; j < TM; ++j) Zt[i][j] = f64x4{0.0, 0.0, 0.0, 0.0};
         double af[2][TM];
 #pragma unroll
-        for (int i = 0; i < TM; ++i) af[0][i] = afrag[(i * KS) * 64 + lane];
+        for (int i = 0; i < TM; ++i) af[0][i] = bfrag[i * 64 + lane];
 #pragma unroll
         for (int kk = 0; kk < KS; ++kk) {
             if (4 * kk < L) {
                 __builtin_amdgcn_sched_barrier(0);
                 if (kk + 1 < KS) {
 #pragma unroll
-                    for (int i = 0; i < TM; ++i) af[(kk + 1) & 1][i] = afrag[(i * KS + kk + 1) * 64 + lane];
+                    for (int i = 0; i < TM; ++i) af[(kk + 1) & 1][i] = bfrag[((kk + 1) * TM + i) * 64 + lane];
                 }
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -200,7 +195,6 @@ void slab_pair_split_kernel(const SlabArgs g) {
     constexpr int KS = 4 * TL, TH = TM / 2, R = 4;
     extern __shared__ __attribute__((aligned(16))) double lds[];
     double* bfrag = lds;                          // [KS][TM][64]
-    double* afrag = lds + KS * TM * 64;           // [TM][KS][64]
     const int L = g.L, M = g.M;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -211,11 +205,6 @@ void slab_pair_split_kernel(const SlabArgs g) {
         const int ln = f & 63, j = (f >> 6) % TM, kk = (f >> 6) / TM;
         const int k = 4 * kk + (ln >> 4), col = 16 * j + (ln & 15);
         bfrag[f] = (k < L && col < M) ? g.B[(int64_t)k * M + col] : 0.0;
-    }
-    for (int f = tid; f < TM * KS * 64; f += 256) {
-        const int ln = f & 63, kk = (f >> 6) % KS, i = (f >> 6) / KS;
-        const int row = 16 * i + (ln & 15), k = 4 * kk + (ln >> 4);
-        afrag[f] = (row < M && k < L) ? g.A[(int64_t)row * L + k] : 0.0;
     }
     __syncthreads();
 
@@ -291,13 +280,13 @@ void slab_pair_split_kernel(const SlabArgs g) {
             for (int j = 0; j < TH; ++j) Zt[i][j] = f64x4{0.0, 0.0, 0.0, 0.0};
         double af[2][TM];
 #pragma unroll
-        for (int i = 0; i < TM; ++i) af[0][i] = afrag[(i * KS) * 64 + lane];
+        for (int i = 0; i < TM; ++i) af[0][i] = bfrag[i * 64 + lane];
 #pragma unroll
         for (int kk = 0; kk < KS; ++kk) {
             __builtin_amdgcn_sched_barrier(0);
             if (kk + 1 < KS) {
 #pragma unroll
-                for (int i = 0; i < TM; ++i) af[(kk + 1) & 1][i] = afrag[(i * KS + kk + 1) * 64 + lane];
+                for (int i = 0; i < TM; ++i) af[(kk + 1) & 1][i] = bfrag[((kk + 1) * TM + i) * 64 + lane];
             }
             __builtin_amdgcn_sched_barrier(0);
             if (4 * kk < L) {
@@ -348,7 +337,7 @@ static int device_cus() {
 template <int TL, int TM>
 static int launch_slab_pair(const SlabArgs& g, hipStream_t stream) {
     const int n_cu = device_cus();
-    const size_t lds = sizeof(double) * 2 * (4 * TL) * TM * 64;
+    const size_t lds = sizeof(double) * (4 * TL) * TM * 64;
     if constexpr (TM % 2 == 0) {
         if (g_slab_pair != 2) {
             // two waves per slab, two workgroups (four slabs in flight) per CU
@@ -364,14 +353,14 @@ static int launch_slab_pair(const SlabArgs& g, hipStream_t stream) {
     return launch_status("slab_pair launch");
 }
 
-// Z[s] = A . X[s] . B for s < nslabs; QS_OK / error after launching, 1 = not eligible.
-int slab_pair_try(int dtype, const void* X, const void* A, const void* B, void* Z, int64_t nslabs, int64_t L,
-                  int64_t M, hipStream_t stream) {
+// Z[s] = B^T . X[s] . B for s < nslabs; QS_OK / error after launching, 1 = not eligible.
+int slab_pair_try(int dtype, const void* X, const void* B, void* Z, int64_t nslabs, int64_t L, int64_t M,
+                  hipStream_t stream) {
     if (!g_slab_pair || dtype != QS_F64) return 1;
     if (L < 1 || M < 1 || L > 64 || M > 64) return 1;
     if (nslabs < 256 || nslabs >= (int64_t(1) << 31)) return 1;    // enough slabs to occupy the waves
     SlabArgs g;
-    g.X = (const double*)X; g.A = (const double*)A; g.B = (const double*)B; g.Z = (double*)Z;
+    g.X = (const double*)X; g.B = (const double*)B; g.Z = (double*)Z;
     g.L = (int)L; g.M = (int)M; g.nslabs = (unsigned)nslabs;
     const int tl = (int)cdiv(L, 16), tm = (int)cdiv(M, 16);
 #define QS_SLAB(TLV)                                                  \
