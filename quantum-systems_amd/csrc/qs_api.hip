@@ -43,13 +43,16 @@ static bool extents_ok(int64_t L, int64_t M) {
 
 static inline char* at(void* base, int64_t elems, size_t es) { return (char*)base + (size_t)elems * es; }
 
-// contractions d, c, b on `rows` leading-index rows
-static int contract_dcb(int dtype, const void* u, const void* C, const void* CT, const void* Ct,
+// contractions d, c, b on `rows` leading-index rows.  `CT` is scratch for C^T: the c contraction of
+// the tiled path multiplies with it; the fused small-basis pass reads C itself and needs no transpose.
+static int contract_dcb(int dtype, const void* u, const void* C, void* CT, const void* Ct,
                         void* T1, void* T2, void* T3, int64_t rows, int64_t L, int64_t M,
                         hipStream_t s) {
     // small bases: d and c in one pass over the tensor (each slab u[a, b] is contiguous)
     int rc = slab_pair_try(dtype, u, C, T2, rows * L, L, M, s);
     if (rc == 1) {
+        rc = transpose_small(dtype, C, CT, L, M, s);
+        if (rc) return rc;
         rc = gemm(dtype, u, C, T1, rows * L * L, M, L, L, M, M, 1, 0, 0, 0, s);
         if (rc) return rc;
         rc = gemm(dtype, CT, T1, T2, M, M, L, L, M, M, rows * L, 0, L * M, M * M, s);
@@ -134,9 +137,7 @@ int qs_transform_two_body(int dtype, const void* u, const void* C, const void* C
     const int64_t wa = (L * L * L * M > L * M * M * M) ? L * L * L * M : L * M * M * M;
     void* WB = (M < L) ? at(WA, wa, es) : out;
 
-    int rc = transpose_small(dtype, C, CT, L, M, s);
-    if (rc) return rc;
-    rc = contract_dcb(dtype, u, C, CT, Ct, /*T1*/ WA, /*T2*/ WB, /*T3*/ WA, L, L, M, s);
+    int rc = contract_dcb(dtype, u, C, CT, Ct, /*T1*/ WA, /*T2*/ WB, /*T3*/ WA, L, L, M, s);
     if (rc) return rc;
     return gemm(dtype, Ct, WA, out, M, M * M * M, L, L, M * M * M, M * M * M, 1, 0, 0, 0, s);
 }
@@ -163,8 +164,6 @@ int qs_transform_two_body_partial(int dtype, const void* u_slab, const void* C, 
     void* CT = work;
     void* T1 = at(work, even_up(L * M), es);
     void* T2 = at(T1, rows * L * L * M, es);
-    int rc = transpose_small(dtype, C, CT, L, M, s);
-    if (rc) return rc;
     return contract_dcb(dtype, u_slab, C, CT, Ct, T1, T2, v_slab, rows, L, M, s);
 }
 
