@@ -460,6 +460,8 @@ int gemm_c128(const double* A, const double* B, double* C, int64_t m, int64_t n,
     if (cfg == 0) {
         int rc = gemm_skinny_try(QS_C128, A, B, C, m, n, k, lda, ldb, ldc, batch, accumulate, stream);
         if (rc != 1) return rc;
+        rc = gemm_stream_try(QS_C128, A, B, C, m, n, k, lda, ldb, ldc, batch, sa, sb, sc, accumulate, stream);
+        if (rc != 1) return rc;
         rc = gemm_fast_try(QS_C128, A, B, C, m, n, k, lda, ldb, ldc, batch, sa, sb, sc,
                            accumulate, g.group_along_m, stream);
         if (rc != 1) return rc;

@@ -1,5 +1,5 @@
 // Small-coefficient streaming product  C[b] (m x n) = A (m x k) . B[b] (k x n)
-// for m, k <= 64 (fp64): the c, b and a contractions of a transform with few
+// for m, k <= 64 (fp64 and complex128): the c, b and a contractions of a transform with few
 // orbitals (BASELINE.json configs[1], l = 55), where A is Ct or C^T and B is
 // the tensor.
 //
@@ -220,6 +220,120 @@ void gemm_stream_left_kernel(const StreamArgs g) {
     }
 }
 
+// complex128 form: one complex element per lane and load (16 bytes), A fragments as separate re / im
+// registers, four MFMAs per fragment pair in the order of the tiled kernels
+// (re += ar.br; im += ar.bi; re += (-ai).bi; im += ai.br).  Two column tiles per block.
+template <int TMW, int SPLIT, int KQ>
+__global__ __launch_bounds__(256, (TMW * KQ > 3 ? 1 : 2))
+void gemm_stream_left_cx_kernel(const StreamArgs g) {
+    constexpr int NKS = 4 * KQ, NT = 2, BW = 16 * NT;
+    using IO = StreamIO<true>;
+
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int c16 = lane & 15, g4 = lane >> 4;
+    const int part = wave % SPLIT;
+    const int row0 = 16 * TMW * part;
+
+    double ar[TMW][NKS], ai[TMW][NKS];
+#pragma unroll
+    for (int i = 0; i < TMW; ++i) {
+#pragma unroll
+        for (int ks = 0; ks < NKS; ++ks) {
+            const int row = row0 + 16 * i + c16, kk = 4 * ks + g4;
+            const bool ok = row < g.m && kk < g.k;
+            const f64x2 v = ok ? *reinterpret_cast<const f64x2*>(g.A + ((int64_t)row * g.lda + kk) * 2) : f64x2{0.0, 0.0};
+            ar[i][ks] = v[0];
+            ai[i][ks] = v[1];
+        }
+    }
+
+    const unsigned w = (blockIdx.x * 4 + wave) / SPLIT, W = gridDim.x * 4 / SPLIT;
+    if (w >= g.total_blocks) return;
+
+    const unsigned b_room = (unsigned)(((int64_t)(g.k - 1) * g.ldb + g.n) * 16);
+    const unsigned c_room = (unsigned)(((int64_t)(g.m - 1) * g.ldc + g.n) * 16);
+    const unsigned kstep = (unsigned)(4 * g.ldb * 16);
+    const unsigned rstep = (unsigned)(4 * g.ldc * 16);
+
+    auto slice = [&](const double* base, int64_t stride, unsigned b, unsigned room) __attribute__((always_inline)) {
+        const uint64_t p = reinterpret_cast<uint64_t>(base + (int64_t)b * stride * 2);
+        const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)p);
+        const uint32_t hi = __builtin_amdgcn_readfirstlane((uint32_t)(p >> 32));
+        return __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void*>(((uint64_t)hi << 32) | lo), (short)0,
+                                                 (int)room, 0x00020000);
+    };
+    auto b_offsets = [&](unsigned cb, unsigned (&off)[NT]) __attribute__((always_inline)) {
+#pragma unroll
+        for (int q = 0; q < NT; ++q) {
+            int col = (int)cb * BW + 16 * q + c16;
+            col = col < g.n - 1 ? col : g.n - 1;
+            off[q] = (unsigned)(g4 * g.ldb + col) * 16u;
+        }
+    };
+
+    unsigned blk_b = w / g.blocks_per_batch, blk_cb = w - blk_b * g.blocks_per_batch;
+    auto rs_next = slice(g.B, g.sb, blk_b, b_room);
+    unsigned off_next[NT];
+    b_offsets(blk_cb, off_next);
+
+    f64x2 ring[NKS][NT];
+#pragma unroll
+    for (int ks = 0; ks < NKS; ++ks)
+#pragma unroll
+        for (int q = 0; q < NT; ++q) ring[ks][q] = IO::load(rs_next, off_next[q] + ks * kstep);
+
+    for (unsigned blk = w; blk < g.total_blocks; blk += W) {
+        const unsigned b = blk_b, cb = blk_cb;
+        const unsigned nxt = blk + W < g.total_blocks ? blk + W : blk;
+        blk_b = nxt / g.blocks_per_batch;
+        blk_cb = nxt - blk_b * g.blocks_per_batch;
+        rs_next = slice(g.B, g.sb, blk_b, b_room);
+        b_offsets(blk_cb, off_next);
+
+        f64x4 cr[TMW][NT], ci[TMW][NT];
+#pragma unroll
+        for (int i = 0; i < TMW; ++i)
+#pragma unroll
+            for (int j = 0; j < NT; ++j) { cr[i][j] = f64x4{0.0, 0.0, 0.0, 0.0}; ci[i][j] = f64x4{0.0, 0.0, 0.0, 0.0}; }
+
+#pragma unroll
+        for (int ks = 0; ks < NKS; ++ks) {
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int i = 0; i < TMW; ++i) {
+#pragma unroll
+                for (int q = 0; q < NT; ++q) {
+                    const double br = ring[ks][q][0], bi = ring[ks][q][1];
+                    cr[i][q] = __builtin_amdgcn_mfma_f64_16x16x4f64(ar[i][ks], br, cr[i][q], 0, 0, 0);
+                    ci[i][q] = __builtin_amdgcn_mfma_f64_16x16x4f64(ar[i][ks], bi, ci[i][q], 0, 0, 0);
+                    cr[i][q] = __builtin_amdgcn_mfma_f64_16x16x4f64(-ai[i][ks], bi, cr[i][q], 0, 0, 0);
+                    ci[i][q] = __builtin_amdgcn_mfma_f64_16x16x4f64(ai[i][ks], br, ci[i][q], 0, 0, 0);
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int q = 0; q < NT; ++q) ring[ks][q] = IO::load(rs_next, off_next[q] + ks * kstep);
+        }
+
+        __builtin_amdgcn_sched_barrier(0);
+        const auto rs_c = slice(g.C, g.sc, b, c_room);
+#pragma unroll
+        for (int q = 0; q < NT; ++q) {
+            const int col = (int)cb * BW + 16 * q + c16;
+            const unsigned o0 = col < g.n ? (unsigned)((row0 + g4) * g.ldc + col) * 16u : 0x80000000u;
+#pragma unroll
+            for (int i = 0; i < TMW; ++i) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const double zr = cr[i][q][r], zi = ci[i][q][r];
+                    IO::store(rs_c, o0 + (unsigned)(4 * i + r) * rstep, zr, zi);
+                }
+            }
+        }
+    }
+}
+
 int g_gemm_stream = 1;   // tuning knob: 0 disables this path, 2 = never split the rows over two waves
 
 template <int TMW, int SPLIT, int KQ, bool VEC>
@@ -250,21 +364,50 @@ static int launch_stream(const StreamArgs& g0, int64_t batch, hipStream_t stream
     return launch_status("gemm_stream launch");
 }
 
+template <int TMW, int SPLIT, int KQ>
+static int launch_stream_cx(const StreamArgs& g0, int64_t batch, hipStream_t stream) {
+    StreamArgs g = g0;
+    const int64_t bpb = cdiv(g.n, 32);
+    const int64_t total = bpb * batch;
+    if (total <= 0 || total >= (int64_t(1) << 30)) return 1;
+    g.blocks_per_batch = (unsigned)bpb;
+    g.total_blocks = (unsigned)total;
+    int n_cu = 256;
+    {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess &&
+            prop.multiProcessorCount > 0)
+            n_cu = prop.multiProcessorCount;
+        else
+            (void)hipGetLastError();
+    }
+    constexpr int WG_PER_CU = (TMW * KQ > 3) ? 1 : 2;
+    int64_t wgs = cdiv(total * SPLIT, 4);
+    if (wgs > (int64_t)WG_PER_CU * n_cu) wgs = (int64_t)WG_PER_CU * n_cu;
+    hipLaunchKernelGGL((gemm_stream_left_cx_kernel<TMW, SPLIT, KQ>), dim3((unsigned)wgs), dim3(256), 0, stream, g);
+    return launch_status("gemm_stream_cx launch");
+}
+
 // QS_OK / error after launching, 1 = not eligible (caller falls back).
 int gemm_stream_try(int dtype, const double* A, const double* B, double* C, int64_t m, int64_t n,
                     int64_t k, int64_t lda, int64_t ldb, int64_t ldc, int64_t batch, int64_t sa,
                     int64_t sb, int64_t sc, int accumulate, hipStream_t stream) {
-    if (!g_gemm_stream || dtype != QS_F64 || accumulate) return 1;
+    if (!g_gemm_stream || accumulate) return 1;
+    if (dtype != QS_F64 && dtype != QS_C128) return 1;
+    const bool cx = dtype == QS_C128;
+    const int64_t esz = cx ? 16 : 8;
     if (m > 64 || k > 64 || m < 1 || k < 1) return 1;
     if (batch > 1 && sa != 0) return 1;                  // A is the shared coefficient matrix
     if (ldb < n || ldc < n) return 1;                    // the range checks assume rows do not overlap
     // 32-bit offsets inside a batch slice, with the "column >= n" marker bit free
-    if (((k + 3) * ldb + n) * 8 >= (int64_t(1) << 31) || ((m + 63) * ldc + n) * 8 >= (int64_t(1) << 31)) return 1;
+    if (((k + 3) * ldb + n) * esz >= (int64_t(1) << 31) || ((m + 63) * ldc + n) * esz >= (int64_t(1) << 31)) return 1;
     if (batch >= (int64_t(1) << 30)) return 1;
-    // a stream long enough to keep every wave busy for a few blocks
-    if (n * batch < (int64_t(1) << 16)) return 1;
-    const bool vec = aligned(B, 16) && aligned(C, 16) && !(ldb & 1) && !(ldc & 1) && !(sb & 1) &&
-                     !(sc & 1) && !(n & 1);
+    // a stream long enough to keep every wave busy for a few blocks.  Measured against the tiled kernels
+    // (profiles/r01_gemm_notes.txt): fp64 wins from l = 32 up (+5...10 %), complex128 only around l = 48
+    // (+13 %; below that the tiled kernel's 32 x 32 shape is faster, at 55 and 64 they are level)
+    if (n * batch < (int64_t(1) << (cx ? 16 : 15))) return 1;
+    if (cx && k > 48) return 1;
     StreamArgs g;
     g.A = A; g.B = B; g.C = C;
     g.lda = lda; g.ldb = ldb; g.ldc = ldc;
@@ -273,6 +416,22 @@ int gemm_stream_try(int dtype, const double* A, const double* B, double* C, int6
     g.blocks_per_batch = 0;
     g.total_blocks = 0;
     const int tm = (int)cdiv(m, 16), kq = (int)cdiv(k, 16);
+    if (cx) {
+        if (!aligned(A, 16) || !aligned(B, 16) || !aligned(C, 16)) return 1;
+#define QS_STREAM_CX(TMWV, SPLITV)                                              \
+        switch (kq) {                                                           \
+            case 1: return launch_stream_cx<TMWV, SPLITV, 1>(g, batch, stream); \
+            case 2: return launch_stream_cx<TMWV, SPLITV, 2>(g, batch, stream); \
+            case 3: return launch_stream_cx<TMWV, SPLITV, 3>(g, batch, stream); \
+            default: return launch_stream_cx<TMWV, SPLITV, 4>(g, batch, stream); \
+        }
+        if (tm == 1) { QS_STREAM_CX(1, 1) }
+        if (tm == 2) { QS_STREAM_CX(2, 1) }
+        QS_STREAM_CX(2, 2)
+#undef QS_STREAM_CX
+    }
+    const bool vec = aligned(B, 16) && aligned(C, 16) && !(ldb & 1) && !(ldc & 1) && !(sb & 1) &&
+                     !(sc & 1) && !(n & 1);
     const bool split = tm > 2 && g_gemm_stream != 2;
 #define QS_STREAM_KQ(TMWV, SPLITV)                                                                         \
     switch (kq) {                                                                                          \

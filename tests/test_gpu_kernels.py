@@ -458,14 +458,18 @@ def test_skinny_product_vs_oracle(K, m, k, cplx):
 # ------------------------------------------- small-coefficient streaming product (qs_gemm_stream.hip)
 
 
+@pytest.mark.parametrize("cplx", [False, True])
 @pytest.mark.parametrize("m,k,n,batch", [(55, 55, 55 * 55, 55), (55, 55, 55, 3025), (64, 64, 4096, 16),
                                           (1, 1, 70000, 1), (17, 3, 1000, 70), (40, 61, 33, 2100),
                                           (64, 5, 100001, 1), (33, 64, 130, 600)])
-def test_stream_product_vs_oracle(K, m, k, n, batch):
+def test_stream_product_vs_oracle(K, m, k, n, batch, cplx):
     # the c, b, a contractions of a small-l transform: A (m x k) is Ct or C^T, shared by the batch
     rng = np.random.default_rng(m * 1000 + k * 10 + batch)
     A = rng.standard_normal((m, k))
     B = rng.standard_normal((batch, k, n))
+    if cplx:
+        A = A + 1j * rng.standard_normal((m, k))
+        B = B + 1j * rng.standard_normal((batch, k, n))
     ref = np.matmul(A, B)
     try:
         K.tuning_set("gemm_stream", 0)
