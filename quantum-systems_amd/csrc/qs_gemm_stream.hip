@@ -372,15 +372,17 @@ static int launch_stream_cx(const StreamArgs& g0, int64_t batch, hipStream_t str
     if (total <= 0 || total >= (int64_t(1) << 30)) return 1;
     g.blocks_per_batch = (unsigned)bpb;
     g.total_blocks = (unsigned)total;
-    int n_cu = 256;
-    {
+    static int n_cu = 0;                              // (the property query costs far more than a launch)
+    if (n_cu == 0) {
         int dev = 0;
         hipDeviceProp_t prop;
         if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess &&
-            prop.multiProcessorCount > 0)
+            prop.multiProcessorCount > 0) {
             n_cu = prop.multiProcessorCount;
-        else
+        } else {
             (void)hipGetLastError();
+            n_cu = 256;
+        }
     }
     constexpr int WG_PER_CU = (TMW * KQ > 3) ? 1 : 2;
     int64_t wgs = cdiv(total * SPLIT, 4);
