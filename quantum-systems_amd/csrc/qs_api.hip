@@ -22,6 +22,22 @@ void note_hip_error(hipError_t e, const char* what) {
     snprintf(g_hip_err, sizeof(g_hip_err), "%s: %s", what, hipGetErrorString(e));
 }
 
+int device_cu_count() {
+    static int n_cu = 0;
+    if (n_cu == 0) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess &&
+            prop.multiProcessorCount > 0) {
+            n_cu = prop.multiProcessorCount;
+        } else {
+            (void)hipGetLastError();
+            n_cu = 256;   // MI355X
+        }
+    }
+    return n_cu;
+}
+
 static int gemm(int dtype, const void* A, const void* B, void* C, int64_t m, int64_t n, int64_t k,
                 int64_t lda, int64_t ldb, int64_t ldc, int64_t batch, int64_t sa, int64_t sb,
                 int64_t sc, hipStream_t s, int accumulate = 0) {

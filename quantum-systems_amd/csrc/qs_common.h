@@ -31,6 +31,10 @@ inline size_t elem_size(int dtype) { return dtype == QS_C128 ? 16 : 8; }
 
 inline bool dtype_ok(int dtype) { return dtype == QS_F64 || dtype == QS_C128; }
 
+// Compute units of the current device (cached: one process drives one GPU; the property query
+// costs far more than a kernel launch).
+int device_cu_count();
+
 // ceil division for positive operands
 inline int64_t cdiv(int64_t a, int64_t b) { return (a + b - 1) / b; }
 

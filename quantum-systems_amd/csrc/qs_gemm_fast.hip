@@ -479,17 +479,7 @@ static int launch_fast(const double* A, const double* B, double* C, int64_t m, i
     if (total <= 0 || total >= (int64_t(1) << 31)) return QS_ERR_BAD_EXTENT;
     g.total = (unsigned)total;
     // two persistent workgroups per CU (the LDS and register budget admits exactly two)
-    static int n_cu = 0;
-    if (n_cu == 0) {
-        int dev = 0;
-        hipDeviceProp_t prop;
-        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) {
-            (void)hipGetLastError();
-            n_cu = 256;
-        } else {
-            n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
-        }
-    }
+    const int n_cu = device_cu_count();
     int64_t P = 2 * (int64_t)n_cu;
     P -= P % 8;
     // How many tiles a workgroup walks (cross-tile prefetch hides the next tile's first loads

@@ -345,17 +345,7 @@ static int launch_stream(const StreamArgs& g0, int64_t batch, hipStream_t stream
     if (total <= 0 || total >= (int64_t(1) << 30)) return 1;
     g.blocks_per_batch = (unsigned)bpb;
     g.total_blocks = (unsigned)total;
-    static int n_cu = 0;
-    if (n_cu == 0) {
-        int dev = 0;
-        hipDeviceProp_t prop;
-        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) {
-            (void)hipGetLastError();
-            n_cu = 256;
-        } else {
-            n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
-        }
-    }
+    const int n_cu = device_cu_count();
     // persistent waves: every wave (pair) walks blocks w, w + W, ...
     constexpr int WG_PER_CU = (TMW * KQ > 8) ? 1 : 2;
     int64_t wgs = cdiv(total * SPLIT, 4);
@@ -372,18 +362,7 @@ static int launch_stream_cx(const StreamArgs& g0, int64_t batch, hipStream_t str
     if (total <= 0 || total >= (int64_t(1) << 30)) return 1;
     g.blocks_per_batch = (unsigned)bpb;
     g.total_blocks = (unsigned)total;
-    static int n_cu = 0;                              // (the property query costs far more than a launch)
-    if (n_cu == 0) {
-        int dev = 0;
-        hipDeviceProp_t prop;
-        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess &&
-            prop.multiProcessorCount > 0) {
-            n_cu = prop.multiProcessorCount;
-        } else {
-            (void)hipGetLastError();
-            n_cu = 256;
-        }
-    }
+    const int n_cu = device_cu_count();
     constexpr int WG_PER_CU = (TMW * KQ > 3) ? 1 : 2;
     int64_t wgs = cdiv(total * SPLIT, 4);
     if (wgs > (int64_t)WG_PER_CU * n_cu) wgs = (int64_t)WG_PER_CU * n_cu;

@@ -319,24 +319,9 @@ void slab_pair_split_kernel(const SlabArgs g) {
 
 int g_slab_pair = 1;   // tuning knob: 0 disables the fused (d, c) pass, 2 = one wave per slab always
 
-static int device_cus() {
-    static int n_cu = 0;
-    if (n_cu == 0) {
-        int dev = 0;
-        hipDeviceProp_t prop;
-        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) {
-            (void)hipGetLastError();
-            n_cu = 256;
-        } else {
-            n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
-        }
-    }
-    return n_cu;
-}
-
 template <int TL, int TM>
 static int launch_slab_pair(const SlabArgs& g, hipStream_t stream) {
-    const int n_cu = device_cus();
+    const int n_cu = device_cu_count();
     const size_t lds = sizeof(double) * (4 * TL) * TM * 64;
     if constexpr (TM % 2 == 0) {
         if (g_slab_pair != 2) {
