@@ -65,7 +65,10 @@ class Workspace:
     """Grow-only device scratch shared by the transforms of one process.
 
     The C ABI never allocates; this keeps one buffer alive between calls so a
-    time loop calling the transform every step does not hit the allocator."""
+    time loop calling the transform every step does not hit the allocator.
+    One buffer per process: calls that share it are meant to be issued on ONE
+    stream (stream order keeps them apart); concurrent streams should call the
+    C ABI with their own workspaces, or use one ``TransformPlan`` each."""
 
     def __init__(self):
         self._buf = None
