@@ -135,3 +135,29 @@ def test_sinc_dvr_change_basis_like_reference():
     assert np.abs(H(got4) - g["u_ctilde"]).max() <= 1e-12 * np.abs(g["u_ctilde"]).max()
     with pytest.raises(AssertionError):
         d4.transform_two_body_elements(d4.u, C, np, anti_symmetrize=True)
+
+
+def test_spin_squared_like_reference():
+    # tests/test_spin.py:136-177 (the part of the reference test that is active): singlet / triplet
+    # expectation values of the two-spin S^2 built from the spinors stored on the spin-doubled ODQD basis;
+    # plus the basis set's one- and two-body spin operators against the oracle's for the same basis
+    import quantum_systems_amd as qsa
+
+    spas = qsa.SpatialOrbitalSystem(2, qsa.ODQD(2, 8, 1001, potential=qsa.ODQD.HOPotential(1)))
+    gos = spas.construct_general_orbital_system(a=[1, 0], b=[0, 1])
+    a, b = H(gos._basis_set.a), H(gos._basis_set.b)
+    aa, ab, ba, bb = np.kron(a, a), np.kron(a, b), np.kron(b, a), np.kron(b, b)
+    S_sq_spin = np.zeros((4, 4))
+    S_sq_spin[0, 0] = S_sq_spin[3, 3] = 2
+    S_sq_spin[1, 1] = S_sq_spin[2, 2] = S_sq_spin[1, 2] = S_sq_spin[2, 1] = 1
+    for trip in (aa, (ab + ba) / np.sqrt(2), bb):
+        np.testing.assert_allclose(trip.T @ S_sq_spin @ trip, 2)
+    singlet = (ab - ba) / np.sqrt(2)
+    np.testing.assert_allclose(singlet.T @ S_sq_spin @ singlet, 0, atol=1e-15)
+
+    st = orc.new_state(2, 1)
+    for k in ("h", "s", "u", "spf", "position"):
+        st[k] = H(getattr(spas, k))
+    ref = orc.change_to_general_orbital_basis(st, a=[1, 0], b=[0, 1])
+    for name in ("spin_x", "spin_y", "spin_z", "spin_2", "spin_2_tb"):
+        np.testing.assert_allclose(H(getattr(gos, name)), ref[name], rtol=1e-12, atol=1e-13)
