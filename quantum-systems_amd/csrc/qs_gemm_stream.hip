@@ -109,6 +109,7 @@ void gemm_stream_left_kernel(const StreamArgs g) {
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int c16 = lane & 15, g4 = lane >> 4;
+    const f64x4 zero4 = {0.0, 0.0, 0.0, 0.0};
     const int part = wave % SPLIT;               // which rows of A this wave multiplies
     const int row0 = 16 * TMW * part;
 
@@ -169,11 +170,7 @@ void gemm_stream_left_kernel(const StreamArgs g) {
         rs_next = slice(g.B, g.sb, blk_b, b_room);
         b_offsets(blk_cb, off_next);
 
-        f64x4 acc[TMW][NT];
-#pragma unroll
-        for (int i = 0; i < TMW; ++i)
-#pragma unroll
-            for (int j = 0; j < NT; ++j) acc[i][j] = f64x4{0.0, 0.0, 0.0, 0.0};
+        f64x4 acc[TMW][NT];                 // k-step 0 starts every accumulator from the literal zero
 
 #pragma unroll
         for (int ks = 0; ks < NKS; ++ks) {
@@ -187,10 +184,10 @@ void gemm_stream_left_kernel(const StreamArgs g) {
 #pragma unroll
                 for (int q = 0; q < NLD; ++q) {
                     if constexpr (VEC) {
-                        acc[i][2 * q] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[i][ks], ring[ks][q][0], acc[i][2 * q], 0, 0, 0);
-                        acc[i][2 * q + 1] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[i][ks], ring[ks][q][1], acc[i][2 * q + 1], 0, 0, 0);
+                        acc[i][2 * q] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[i][ks], ring[ks][q][0], ks == 0 ? zero4 : acc[i][2 * q], 0, 0, 0);
+                        acc[i][2 * q + 1] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[i][ks], ring[ks][q][1], ks == 0 ? zero4 : acc[i][2 * q + 1], 0, 0, 0);
                     } else {
-                        acc[i][q] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[i][ks], ring[ks][q], acc[i][q], 0, 0, 0);
+                        acc[i][q] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[i][ks], ring[ks][q], ks == 0 ? zero4 : acc[i][q], 0, 0, 0);
                     }
                 }
             }
@@ -232,6 +229,7 @@ void gemm_stream_left_cx_kernel(const StreamArgs g) {
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int c16 = lane & 15, g4 = lane >> 4;
+    const f64x4 zero4 = {0.0, 0.0, 0.0, 0.0};
     const int part = wave % SPLIT;
     const int row0 = 16 * TMW * part;
 
@@ -291,11 +289,7 @@ void gemm_stream_left_cx_kernel(const StreamArgs g) {
         rs_next = slice(g.B, g.sb, blk_b, b_room);
         b_offsets(blk_cb, off_next);
 
-        f64x4 cr[TMW][NT], ci[TMW][NT];
-#pragma unroll
-        for (int i = 0; i < TMW; ++i)
-#pragma unroll
-            for (int j = 0; j < NT; ++j) { cr[i][j] = f64x4{0.0, 0.0, 0.0, 0.0}; ci[i][j] = f64x4{0.0, 0.0, 0.0, 0.0}; }
+        f64x4 cr[TMW][NT], ci[TMW][NT];     // k-step 0 starts every accumulator from the literal zero
 
 #pragma unroll
         for (int ks = 0; ks < NKS; ++ks) {
@@ -305,8 +299,8 @@ void gemm_stream_left_cx_kernel(const StreamArgs g) {
 #pragma unroll
                 for (int q = 0; q < NT; ++q) {
                     const double br = ring[ks][q][0], bi = ring[ks][q][1];
-                    cr[i][q] = __builtin_amdgcn_mfma_f64_16x16x4f64(ar[i][ks], br, cr[i][q], 0, 0, 0);
-                    ci[i][q] = __builtin_amdgcn_mfma_f64_16x16x4f64(ar[i][ks], bi, ci[i][q], 0, 0, 0);
+                    cr[i][q] = __builtin_amdgcn_mfma_f64_16x16x4f64(ar[i][ks], br, ks == 0 ? zero4 : cr[i][q], 0, 0, 0);
+                    ci[i][q] = __builtin_amdgcn_mfma_f64_16x16x4f64(ar[i][ks], bi, ks == 0 ? zero4 : ci[i][q], 0, 0, 0);
                     cr[i][q] = __builtin_amdgcn_mfma_f64_16x16x4f64(-ai[i][ks], bi, cr[i][q], 0, 0, 0);
                     ci[i][q] = __builtin_amdgcn_mfma_f64_16x16x4f64(ai[i][ks], br, ci[i][q], 0, 0, 0);
                 }

@@ -57,6 +57,7 @@ void slab_pair_kernel(const SlabArgs g) {
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int c16 = lane & 15, g4 = lane >> 4;
+    const f64x4 zero4 = {0.0, 0.0, 0.0, 0.0};
 
     for (int f = tid; f < KS * TM * 64; f += 256) {
         const int ln = f & 63, j = (f >> 6) % TM, kk = (f >> 6) / TM;
@@ -101,11 +102,7 @@ void slab_pair_kernel(const SlabArgs g) {
         const auto rs_next = rsrc(g.X, nxt, x_slab, x_slab);
 
         // ---- Y = X . B : row tiles of X, all column tiles of B
-        f64x4 Y[TL][TM];
-#pragma unroll
-        for (int i = 0; i < TL; ++i)
-#pragma unroll
-            for (int j = 0; j < TM; ++j) Y[i][j] = f64x4{0.0, 0.0, 0.0, 0.0};
+        f64x4 Y[TL][TM];      // (k-step 0 starts every accumulator from the literal zero)
         // (fragments of k-step kk + 1 are read from LDS while k-step kk multiplies; k-steps that lie
         // wholly in the padding, 4 kk >= L, are skipped: wave-uniform branches)
         double bf[2][TM];
@@ -113,7 +110,7 @@ void slab_pair_kernel(const SlabArgs g) {
         for (int j = 0; j < TM; ++j) bf[0][j] = bfrag[j * 64 + lane];
 #pragma unroll
         for (int kk = 0; kk < KS; ++kk) {
-            if (4 * kk < L) {
+            if (kk == 0 || 4 * kk < L) {          // (k-step 0 always runs: it also zeroes the accumulators)
                 __builtin_amdgcn_sched_barrier(0);
                 if (kk + 1 < KS) {
 #pragma unroll
@@ -126,7 +123,7 @@ void slab_pair_kernel(const SlabArgs g) {
                     const double xa = k_ok ? xr[i][kk] : 0.0;
 #pragma unroll
                     for (int j = 0; j < TM; ++j)
-                        Y[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(xa, bf[kk & 1][j], Y[i][j], 0, 0, 0);
+                        Y[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(xa, bf[kk & 1][j], kk == 0 ? zero4 : Y[i][j], 0, 0, 0);
                 }
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -136,16 +133,12 @@ void slab_pair_kernel(const SlabArgs g) {
 
         // ---- Z = A . Y : register r of row tile i of Y is the B fragment of k-step 4 i + r
         f64x4 Zt[TM][TM];
-#pragma unroll
-        for (int i = 0; i < TM; ++i)
-#pragma unroll
-            for (int j = 0; j < TM; ++j) Zt[i][j] = f64x4{0.0, 0.0, 0.0, 0.0};
         double af[2][TM];
 #pragma unroll
         for (int i = 0; i < TM; ++i) af[0][i] = bfrag[i * 64 + lane];
 #pragma unroll
         for (int kk = 0; kk < KS; ++kk) {
-            if (4 * kk < L) {
+            if (kk == 0 || 4 * kk < L) {          // (k-step 0 always runs: it also zeroes the accumulators)
                 __builtin_amdgcn_sched_barrier(0);
                 if (kk + 1 < KS) {
 #pragma unroll
@@ -156,7 +149,7 @@ void slab_pair_kernel(const SlabArgs g) {
                 for (int i = 0; i < TM; ++i)
 #pragma unroll
                     for (int j = 0; j < TM; ++j)
-                        Zt[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[kk & 1][i], Y[kk >> 2][j][kk & 3], Zt[i][j], 0, 0, 0);
+                        Zt[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[kk & 1][i], Y[kk >> 2][j][kk & 3], kk == 0 ? zero4 : Zt[i][j], 0, 0, 0);
             }
         }
         __builtin_amdgcn_sched_barrier(0);
@@ -199,6 +192,7 @@ void slab_pair_split_kernel(const SlabArgs g) {
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int c16 = lane & 15, g4 = lane >> 4;
+    const f64x4 zero4 = {0.0, 0.0, 0.0, 0.0};
     const int half = wave & 1, j0 = half * TH;
 
     for (int f = tid; f < KS * TM * 64; f += 256) {
@@ -240,11 +234,7 @@ void slab_pair_split_kernel(const SlabArgs g) {
         const auto rs_cur = rsrc(g.X, s, x_slab, x_slab);
         const auto rs_next = rsrc(g.X, nxt, x_slab, x_slab);
 
-        f64x4 Y[TL][TH];
-#pragma unroll
-        for (int i = 0; i < TL; ++i)
-#pragma unroll
-            for (int j = 0; j < TH; ++j) Y[i][j] = f64x4{0.0, 0.0, 0.0, 0.0};
+        f64x4 Y[TL][TH];      // (k-step 0 starts every accumulator from the literal zero)
         double bf[2][TH];
 #pragma unroll
         for (int j = 0; j < TH; ++j) bf[0][j] = bfrag[(j0 + j) * 64 + lane];
@@ -256,14 +246,14 @@ void slab_pair_split_kernel(const SlabArgs g) {
                 for (int j = 0; j < TH; ++j) bf[(kk + 1) & 1][j] = bfrag[((kk + 1) * TM + j0 + j) * 64 + lane];
             }
             __builtin_amdgcn_sched_barrier(0);
-            if (4 * kk < L) {                          // (a k-step wholly in the padding multiplies nothing)
+            if (kk == 0 || 4 * kk < L) {               // (a k-step wholly in the padding multiplies nothing)
                 const bool k_ok = 4 * kk + g4 < L;
 #pragma unroll
                 for (int i = 0; i < TL; ++i) {
                     const double xa = k_ok ? xr[i][kk & 3] : 0.0;
 #pragma unroll
                     for (int j = 0; j < TH; ++j)
-                        Y[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(xa, bf[kk & 1][j], Y[i][j], 0, 0, 0);
+                        Y[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(xa, bf[kk & 1][j], kk == 0 ? zero4 : Y[i][j], 0, 0, 0);
                 }
             }
             __builtin_amdgcn_sched_barrier(0);
@@ -274,10 +264,6 @@ void slab_pair_split_kernel(const SlabArgs g) {
         }
 
         f64x4 Zt[TM][TH];
-#pragma unroll
-        for (int i = 0; i < TM; ++i)
-#pragma unroll
-            for (int j = 0; j < TH; ++j) Zt[i][j] = f64x4{0.0, 0.0, 0.0, 0.0};
         double af[2][TM];
 #pragma unroll
         for (int i = 0; i < TM; ++i) af[0][i] = bfrag[i * 64 + lane];
@@ -289,12 +275,12 @@ void slab_pair_split_kernel(const SlabArgs g) {
                 for (int i = 0; i < TM; ++i) af[(kk + 1) & 1][i] = bfrag[((kk + 1) * TM + i) * 64 + lane];
             }
             __builtin_amdgcn_sched_barrier(0);
-            if (4 * kk < L) {
+            if (kk == 0 || 4 * kk < L) {
 #pragma unroll
                 for (int i = 0; i < TM; ++i)
 #pragma unroll
                     for (int j = 0; j < TH; ++j)
-                        Zt[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[kk & 1][i], Y[kk >> 2][j][kk & 3], Zt[i][j], 0, 0, 0);
+                        Zt[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[kk & 1][i], Y[kk >> 2][j][kk & 3], kk == 0 ? zero4 : Zt[i][j], 0, 0, 0);
             }
         }
         __builtin_amdgcn_sched_barrier(0);
