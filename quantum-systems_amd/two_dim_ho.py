@@ -139,22 +139,31 @@ def spf_state(r, theta, p, mass, omega, indices_nm=None):
 
 
 def _laguerre_coefficients(n, alpha):
-    """c_i of L_n^alpha(t) = sum_i c_i t^i."""
-    return [(-1) ** i * math.comb(n + alpha, n - i) / math.factorial(i) for i in range(n + 1)]
+    """Exact c_i of L_n^alpha(t) = sum_i c_i t^i (rationals)."""
+    from fractions import Fraction
+
+    return [Fraction((-1) ** i * math.comb(n + alpha, n - i), math.factorial(i)) for i in range(n + 1)]
 
 
 def radial_integral(n_p, m_p, n_q, m_q, mass, omega, order=1):
     """``int_0^inf r^(1+order) R_p(r) R_q(r) dr`` of two radial functions
     (two_dim_helper.py:53-67, sympy there).  With t = a^2 r^2 the integrand is
-    a polynomial in t times t^((order+|m_p|+|m_q|)/2) exp(-t)."""
+    a polynomial in t times t^((order+|m_p|+|m_q|)/2) exp(-t): a finite sum of
+    Gamma(base + i + j) = Gamma(base) (base)_(i+j).  The alternating sum is
+    done in exact rational arithmetic (it cancels to zero for many orbital
+    pairs; in floating point the terms of ~1e12 would leave ~1e-9 behind) and
+    only the common factor Gamma(base) is a float."""
+    from fractions import Fraction
+
     a = bohr_radius(mass, omega)
     mp, mq = abs(m_p), abs(m_q)
-    base = 0.5 * (order + mp + mq) + 1.0
-    total = 0.0
-    for i, ci in enumerate(_laguerre_coefficients(n_p, mp)):
-        for j, cj in enumerate(_laguerre_coefficients(n_q, mq)):
-            total += ci * cj * scipy.special.gamma(base + i + j)
-    return total / (2.0 * a ** (2 + order))
+    base = Fraction(order + mp + mq, 2) + 1
+    cp, cq = _laguerre_coefficients(n_p, mp), _laguerre_coefficients(n_q, mq)
+    rising = [Fraction(1)]                               # (base)_k = base (base+1) ... (base+k-1)
+    for k in range(len(cp) + len(cq) - 2):
+        rising.append(rising[-1] * (base + k))
+    total = sum(ci * cj * rising[i + j] for i, ci in enumerate(cp) for j, cj in enumerate(cq))
+    return float(total) * scipy.special.gamma(float(base)) / (2.0 * a ** (2 + order))
 
 
 def theta_1_integral(m_p, m_q):
