@@ -108,3 +108,37 @@ def test_random_transforms_match_oracle(case):
     part = K.transform_two_body_partial(dev(u[lo:lo + rows]), dev(C), dev(Ct_eff)).cpu().numpy()
     ref_part = orc.transform_two_body_dcb(u[lo:lo + rows], C, Ct_eff)
     assert np.abs(part - ref_part).max() <= 1e-12 * max(1e-300, float(np.abs(ref_part).max()))
+
+
+@given(st.integers(1, 40), st.booleans(), st.booleans(), st.booleans(), st.integers(0, 2**31 - 1), st.data())
+@settings(max_examples=int(os.environ.get("QS_HYP_EXAMPLES", "40")), deadline=None,
+          suppress_health_check=list(HealthCheck))
+def test_random_spin_expansions_are_value_exact(l, cplx_in, cplx_out, anti, seed, data):
+    # the bandwidth kernels against their definitions (basis_set.py:772-778, :634), value-exact:
+    # any l, any p-slab, real/complex in and out, with and without the fused anti-symmetrisation,
+    # and the stand-alone anti-symmetrisation in and out of place
+    from quantum_systems_amd import kernels as K
+
+    if cplx_in and not cplx_out:
+        cplx_out = True
+    rng = np.random.default_rng(seed)
+    u = rng.standard_normal((l,) * 4)
+    if cplx_in:
+        u = u + 1j * rng.standard_normal((l,) * 4)
+    p_lo = data.draw(st.integers(0, l - 1))
+    p_hi = data.draw(st.integers(p_lo + 1, l))
+    eye = np.eye(2)
+    ref = np.einsum("pqrs,ac,bd->paqbrcsd", u[p_lo:p_hi], eye, eye).reshape(2 * (p_hi - p_lo), 2 * l, 2 * l, 2 * l)
+    if anti:
+        ref = ref - ref.transpose(0, 1, 3, 2)
+    if cplx_out:
+        ref = ref.astype(np.complex128)
+    du = torch.from_numpy(u).cuda()
+    got = K.spin_expand_two_body(du, antisymmetrize=anti, out_dtype=torch.complex128 if cplx_out else None,
+                                 p_lo=p_lo, p_hi=p_hi).cpu().numpy()
+    assert got.dtype == ref.dtype and np.array_equal(got, ref)
+    a_ref = u - u.transpose(0, 1, 3, 2)
+    assert np.array_equal(K.antisymmetrize(du).cpu().numpy(), a_ref)
+    dv = du.clone()
+    K.antisymmetrize(dv, out=dv)
+    assert np.array_equal(dv.cpu().numpy(), a_ref)
