@@ -41,7 +41,7 @@ def parse():
     ap.add_argument("--layout", choices=["replicated", "sharded"], default="replicated")
     ap.add_argument("--gather", action="store_true", help="include the all-gather of the result")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-l", type=int, default=176, help="largest size of the CPU-baseline sample")
+    ap.add_argument("--cpu-l", type=int, default=192, help="largest size of the CPU-baseline sample")
     ap.add_argument("--no-probes", action="store_true")
     ap.add_argument("--workload", choices=["transform", "spin_expand", "antisymmetrize"], default="transform",
                     help="transform = the headline metric; the other two are the HBM-bound kernels of "
@@ -125,7 +125,7 @@ def cpu_baseline(l_max, budget_s=15.0):
 
     run(32)                                   # BLAS thread pool warm-up
     l, dt = 64, run(64)
-    while dt < budget_s / 3 and l < l_max:    # grow the sample until it is worth ~budget_s
+    while dt < 0.6 * budget_s and l < l_max:  # grow the sample until it is worth 10-20 s
         nxt = int(min(l_max, max(l + 16, l * (budget_s / max(dt, 1e-3)) ** 0.2)))
         nxt -= nxt % 8
         if nxt <= l:
