@@ -18,6 +18,11 @@ namespace qs {
 
 typedef double f64x2 __attribute__((ext_vector_type(2)));
 
+// Store that will not be read again soon: bypasses the write-back path of L2 (measured on the
+// anti-symmetrisation: 5.41 -> 5.77 TB/s at l = 256; the spin expansion, whose lanes fill a line from
+// several instructions, LOSES 4 % with it and keeps plain stores).
+template <typename T> __device__ __forceinline__ void stream_store(T* p, T v) { __builtin_nontemporal_store(v, p); }
+
 static constexpr int PT = 32;        // tile edge (elements)
 static constexpr int PS = PT + 1;    // LDS row stride
 
@@ -71,15 +76,15 @@ __global__ __launch_bounds__(256) void antisym_kernel(const T* __restrict__ u, T
 #pragma unroll
         for (int rr = ty; rr < PT; rr += 8) {
             const int r = ti * PT + rr, c = tj * PT + tx;
-            if (r < l && c < l) o[(int64_t)r * l + c] = t1[rr][tx] - t1[tx][rr];
+            if (r < l && c < l) stream_store(&o[(int64_t)r * l + c], (T)(t1[rr][tx] - t1[tx][rr]));
         }
     } else {
 #pragma unroll
         for (int rr = ty; rr < PT; rr += 8) {
             int r = ti * PT + rr, c = tj * PT + tx;
-            if (r < l && c < l) o[(int64_t)r * l + c] = t1[rr][tx] - t2[tx][rr];
+            if (r < l && c < l) stream_store(&o[(int64_t)r * l + c], (T)(t1[rr][tx] - t2[tx][rr]));
             r = tj * PT + rr; c = ti * PT + tx;
-            if (r < l && c < l) o[(int64_t)r * l + c] = t2[rr][tx] - t1[tx][rr];
+            if (r < l && c < l) stream_store(&o[(int64_t)r * l + c], (T)(t2[rr][tx] - t1[tx][rr]));
         }
     }
 }
