@@ -47,3 +47,23 @@ def test_bandwidth_lines(workload):
         assert key in d, key
     assert d["unit"] == "GB/s" and d["roofline"]["bound"] == "hbm" and d["roofline"]["peak"] == 8000.0
     assert d["parity"]["value_exact_vs_definition"] is True
+
+
+@pytest.mark.parametrize("layout", ["replicated", "sharded"])
+def test_two_rank_launch_on_one_device(layout):
+    # the N > 1 code path as the driver launches it (torch.distributed.run, one process per rank), rehearsed
+    # on ONE GPU: both ranks on cuda:0 over gloo (QS_BENCH_SINGLE_DEVICE / QS_BENCH_BACKEND are rehearsal
+    # hooks; the driver's real run uses one GPU per rank and RCCL)
+    env = dict(os.environ, QS_BENCH_SINGLE_DEVICE="1", QS_BENCH_BACKEND="gloo", MASTER_ADDR="127.0.0.1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+           "--master-addr", "127.0.0.1", "--master-port", "29671" if layout == "replicated" else "29672",
+           os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--orbitals", "64",
+           "--layout", layout, "--no-cpu-baseline", "--no-probes"]
+    res = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=ROOT, env=env)
+    assert res.returncode == 0, res.stderr[-3000:]
+    lines = [ln for ln in res.stdout.splitlines() if ln.strip().startswith("{")]
+    assert len(lines) == 1, res.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["value"] > 0
+    if layout == "replicated":
+        assert d["parity"]["randomised_identity_rel_diff"] <= 1e-10
