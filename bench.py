@@ -1,7 +1,8 @@
 """Headline benchmark: four-index transform of the two-body integrals.
 
     python bench.py [--gpus N --steps K --warmup W] [--orbitals 256] [--dtype f64|c128]
-                    [--layout replicated|sharded] [--gather] [--no-cpu-baseline]
+                    [--layout auto|replicated|sharded|inplace] [--gather] [--fresh-c auto|on|off]
+                    [--workload transform|spin_expand|antisymmetrize] [--no-cpu-baseline]
 
 Metric (BASELINE.json): "4-index u transform TFLOP/s (fp64) at L orbitals".
 A step is ONE full transform out = Ct Ct u C C of a synthetic RandomBasisSet-
@@ -9,18 +10,30 @@ shaped tensor resident in HBM (BASELINE.json configs[2]: real fp64, l=256,
 u = 34.4 GB, C = real orthogonal).  The work figure is the algorithmic
 8 l^5 flops (32 l^5 for complex128), whatever the kernels actually do.
 
-N > 1 (launched by torch.distributed.run, one rank per GPU, RCCL): the SAME
-l=256 problem, output sharded over its leading index p ("strong" scaling).
-Default layout: u replicated on every GPU, no collective on the data path
-(SURVEY 8e); --layout sharded keeps u sharded over its second index and does
-one all-to-all; --gather adds the all-gather that replicates the result.
+N > 1: one process per GPU over RCCL.  Either the driver launches the ranks
+(`python -m torch.distributed.run ... bench.py --gpus N`: RANK / WORLD_SIZE come
+from the environment) or `python bench.py --gpus N` alone: then THIS process
+starts the N rank processes itself -- fresh children, before anything here has
+touched the GPU or imported torch -- waits for them and relays rank 0's JSON
+line.  The SAME l=256 problem at every N ("strong" scaling), result sharded
+over its leading index p.  Layouts:
+  replicated  u resident on every GPU, no collective on the data path (default
+              when u fits: 34 GB of 288);
+  sharded     u sharded over its second index, one all-to-all, out of place;
+  inplace     the same exchange inside the output buffer: input slab + output
+              slab + O(l^3) per GPU -- the form BASELINE.json configs[4]
+              (l=512 complex128, 1.1 TB) needs; slabs are generated per rank.
+The north star's single all-gather (replicating the p-sharded result) is timed
+as a second leg and reported next to the no-collective value; `--gather` makes
+it part of `value`.
 
-Prints ONE JSON line on rank 0.
+Prints ONE JSON line on rank 0; exits non-zero if the parity property fails.
 """
 
 import argparse
 import json
 import os
+import subprocess
 import sys
 import time
 
@@ -28,9 +41,12 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 MFMA_F64_PEAK_TFLOPS = 78.6   # 256 CU x 4 SIMD x 2048 flop / 64 clk x 2.4 GHz (MI355X_MICROARCH.md clocks)
+HBM_PEAK_GBPS = 8000.0        # MI355X_MICROARCH.md: 8 TB/s spec (6.3 TB/s measured achievable)
+PARITY_BOUND = 1e-10          # BASELINE.json north_star: <= 1e-10 relative fp64
+HBM_BYTES = 288e9
 
 
-def parse():
+def parse(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
@@ -38,15 +54,84 @@ def parse():
     ap.add_argument("--orbitals", "-l", dest="l", type=int, default=256,
                     help="number of orbitals l (named so that torch.distributed.run does not read it as --l*)")
     ap.add_argument("--dtype", choices=["f64", "c128"], default="f64")
-    ap.add_argument("--layout", choices=["replicated", "sharded"], default="replicated")
-    ap.add_argument("--gather", action="store_true", help="include the all-gather of the result")
+    ap.add_argument("--layout", choices=["auto", "replicated", "sharded", "inplace"], default="auto")
+    ap.add_argument("--gather", action="store_true", help="make the all-gather of the result part of `value`")
+    ap.add_argument("--no-gather-leg", action="store_true", help="skip the second, gather-inclusive timing leg at N > 1")
+    ap.add_argument("--fresh-c", choices=["auto", "on", "off"], default="auto",
+                    help="a new coefficient matrix every step, C_tilde derived inside the call (the per-step caller "
+                         "system.py:222-225); auto = on for complex128 (time evolution), off for fp64 (one change_basis)")
+    ap.add_argument("--staging-rows", type=int, default=1, help="rows per all-to-all of the in-place exchange")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-l", type=int, default=192, help="largest size of the CPU-baseline sample")
+    ap.add_argument("--cpu-full", action="store_true", help="also time the CPU baseline at the full l (one repetition)")
     ap.add_argument("--no-probes", action="store_true")
     ap.add_argument("--workload", choices=["transform", "spin_expand", "antisymmetrize"], default="transform",
                     help="transform = the headline metric; the other two are the HBM-bound kernels of "
                          "BASELINE.json configs[3] (own metric names, same JSON shape)")
-    return ap.parse_args()
+    return ap.parse_args(argv)
+
+
+# ----------------------------------------------------------------------------------------------
+# self-launch: `python bench.py --gpus N` without an external launcher
+# ----------------------------------------------------------------------------------------------
+
+def self_launch(n):
+    """Start the N rank processes (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* in their environment, as
+    torch.distributed.run would set them), wait, relay rank 0's stdout.  This parent never imports torch
+    and never touches the GPU; the children are fresh processes (no exec of a GPU-initialised process)."""
+    import socket
+    import threading
+
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    base = dict(os.environ, WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1",
+                MASTER_PORT=str(port), QS_BENCH_SELF_LAUNCHED="1")
+    base.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    procs, rank0_out = [], []
+    for r in range(n):
+        env = dict(base, RANK=str(r), LOCAL_RANK=str(r))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=subprocess.PIPE if r == 0 else sys.stderr, text=True if r == 0 else None))
+
+    def drain():
+        for ln in procs[0].stdout:
+            rank0_out.append(ln)
+
+    reader = threading.Thread(target=drain, daemon=True)
+    reader.start()
+    failed = 0
+    live = set(range(n))
+    while live:
+        for r in sorted(live):
+            rc = procs[r].poll()
+            if rc is None:
+                continue
+            live.discard(r)
+            if rc != 0 and not failed:
+                failed = rc
+                print(f"bench.py: rank {r} exited with {rc}; stopping the other ranks", file=sys.stderr)
+                for o in live:
+                    procs[o].terminate()          # exactly the PIDs started above
+        time.sleep(0.05)
+    reader.join(timeout=10)
+    for ln in rank0_out:
+        (sys.stdout if ln.lstrip().startswith("{") else sys.stderr).write(ln)
+    sys.stdout.flush()
+    return failed
+
+
+# ----------------------------------------------------------------------------------------------
+# synthetic inputs
+# ----------------------------------------------------------------------------------------------
+
+def make_unitary(torch, l, dtype, device, seed):
+    g = torch.Generator(device=device).manual_seed(seed)
+    a = torch.randn((l, l), dtype=torch.float64, device=device, generator=g)
+    if dtype.is_complex:
+        a = torch.complex(a, torch.randn((l, l), dtype=torch.float64, device=device, generator=g))
+    C, _ = torch.linalg.qr(a)
+    return C.contiguous()
 
 
 def make_inputs(torch, l, dtype, device, seed=1234):
@@ -79,26 +164,73 @@ def make_inputs(torch, l, dtype, device, seed=1234):
     return u, C, Ct
 
 
-def identity_check(torch, u, out_rows, C, Ct, p_lo, seed=7):
-    """Size-independent parity property: contract both sides with
-    random vectors; O(l^4) each.  Returns the relative difference."""
-    l, dt = C.shape[0], u.dtype
-    g = torch.Generator(device=u.device).manual_seed(seed)
-    vs = [torch.randn(l, dtype=torch.float64, device=u.device, generator=g).to(dt) for _ in range(4)]
-    x, y, z, w = vs
+def make_u_slab(torch, l, dtype, device, axis, lo, hi, seed=1234, centre=False):
+    """Rows [lo, hi) of axis 0 or 1 of a synthetic (l,l,l,l) tensor, generated ON THIS RANK ONLY (no rank
+    ever allocates the whole tensor: l=512 complex128 is 1.1 TB).  Uniform [0,1) re and im like
+    random_basis.py:52-69; the (p,q,r,s)<->(q,p,s,r) symmetrisation needs the partner slab of another rank and
+    is skipped -- the transform and its parity property do not depend on it.  Element
+    values depend on (seed, leading index, slab bounds) only."""
+    n = hi - lo
+    shape = (n, l, l, l) if axis == 0 else (l, n, l, l)
+    u = torch.empty(shape, dtype=dtype, device=device)
+    rdt = torch.float64
+    per_row = shape[1] * l * l
+    step = max(1, (1 << 27) // per_row)
+    for a0 in range(0, shape[0], step):
+        a1 = min(shape[0], a0 + step)
+        first = (lo + a0) if axis == 0 else (a0 + 7919 * lo)
+        g = torch.Generator(device=device).manual_seed(seed * 1000003 + first)
+        sub = (a1 - a0,) + shape[1:]
+        blk = torch.rand(sub, dtype=rdt, device=device, generator=g)
+        if centre:
+            blk -= 0.5
+        if dtype.is_complex:
+            blk = torch.complex(blk, torch.rand(sub, dtype=rdt, device=device, generator=g))
+        u[a0:a1] = blk
+    return u
+
+
+def contract4(t, va, vb, vc, vd):
+    """sum_abcd t[a,b,c,d] va[a] vb[b] vc[c] vd[d] as four matrix-vector products (no tensor-sized temporary)."""
+    A, B, C, D = t.shape
+    x = t.reshape(-1, D) @ vd
+    x = x.reshape(-1, C) @ vc
+    x = x.reshape(A, B) @ vb
+    return x @ va
+
+
+def identity_parts(torch, u_part, out_rows, C, Ct, p_lo, b_lo=None, seed=7):
+    """Size-independent parity property: contract both sides with random vectors x, y, z, w,
+        sum out[pqrs] x_p y_q z_r w_s  ==  sum u[abcd] (Ct^T x)_a (Ct^T y)_b (C z)_c (C w)_d,
+    O(l^4) each.  Returns this rank's partial sums (lhs over its rows p of `out`; rhs over the part of u it
+    holds: everything with x restricted to its rows when u is whole, its b-slab when u is b-sharded); the sums
+    over ranks are compared."""
+    l, dt = C.shape[0], out_rows.dtype
+    g = torch.Generator(device=out_rows.device).manual_seed(seed)
+    x, y, z, w = [torch.randn(l, dtype=torch.float64, device=out_rows.device, generator=g).to(dt) for _ in range(4)]
     pc = out_rows.shape[0]
-    lhs = torch.einsum("pqrs,p,q,r,s->", out_rows, x[p_lo:p_lo + pc], y, z, w)
-    # restrict the x-contraction to this rank's rows of Ct
-    xa = Ct[p_lo:p_lo + pc].transpose(0, 1) @ x[p_lo:p_lo + pc]
-    rhs = torch.einsum("abcd,a,b,c,d->", u, xa, Ct.transpose(0, 1) @ y, C @ z, C @ w)
+    C, Ct = C.to(dt), Ct.to(dt)
+    lhs = contract4(out_rows, x[p_lo:p_lo + pc], y, z, w)
+    yb, zc, wd = Ct.transpose(0, 1) @ y, C @ z, C @ w
+    if b_lo is None:      # whole u on this rank: restrict the x-contraction to this rank's rows of Ct
+        xa = Ct[p_lo:p_lo + pc].transpose(0, 1) @ x[p_lo:p_lo + pc]
+        rhs = contract4(u_part.to(dt) if u_part.dtype != dt else u_part, xa, yb, zc, wd)
+    else:                 # u[:, b_lo:b_hi] on this rank
+        xa = Ct.transpose(0, 1) @ x
+        rhs = contract4(u_part, xa, yb[b_lo:b_lo + u_part.shape[1]], zc, wd)
     return lhs, rhs
 
 
-def cpu_baseline(l_max, budget_s=15.0):
-    """The oracle (NumPy restatement of basis_set.py:341-348) timed on the
-    host cores of this box on a bounded sample of the same workload: a pilot
-    at l=48 sizes the sample so that it takes roughly `budget_s` seconds
-    (time ~ l^5), capped at l_max."""
+# ----------------------------------------------------------------------------------------------
+# CPU baseline (the oracle, timed on the host cores of this box)
+# ----------------------------------------------------------------------------------------------
+
+def cpu_baseline(l_max, budget_s=15.0, full_l=None):
+    """The oracle (NumPy restatement of basis_set.py:341-348: tensordot x4) on the host cores of this box on
+    a bounded sample of the same workload.  Fixed points at l=55 (BASELINE.json configs[1]) and l=128 with the
+    5-operand numpy.einsum(optimize=True) form the reference's tests use (tests/test_custom_system.py:19-24)
+    beside them, then a sample grown until it is worth ~`budget_s` seconds (time ~ l^5), capped at l_max;
+    `value` is the largest tensordot sample.  `full_l`: one repetition at the full size (opt-in, ~1 min at 256)."""
     import numpy as np
 
     from oracle import qs_oracle as orc
@@ -112,129 +244,62 @@ def cpu_baseline(l_max, budget_s=15.0):
     except Exception:
         threads, blas = os.cpu_count() or 1, "unknown"
 
-    def run(l):
+    def inputs(l):
         rng = np.random.default_rng(0)
         u = rng.random((l, l, l, l))
         u = 0.5 * (u + u.transpose(1, 0, 3, 2))
         C, _ = np.linalg.qr(rng.standard_normal((l, l)))
+        return u, C
+
+    def run(l, einsum=False):
+        u, C = inputs(l)
         t0 = time.perf_counter()
         out = orc.transform_two_body(u, C)
         dt = time.perf_counter() - t0
         assert out.shape == (l, l, l, l)
-        return dt
+        dte = None
+        if einsum:
+            Ct = C.conj().T
+            t0 = time.perf_counter()
+            ref = np.einsum("pa,qb,abcd,cr,ds->pqrs", Ct, Ct, u, C, C, optimize=True)
+            dte = time.perf_counter() - t0
+            assert np.abs(ref - out).max() <= 1e-10 * np.abs(ref).max()
+        return dt, dte
 
     run(32)                                   # BLAS thread pool warm-up
-    l, dt = 64, run(64)
+    points = []
+    for lp in (55, 128):
+        if lp <= max(l_max, 55):
+            dt, dte = run(lp, einsum=True)
+            fl = orc.transform_flops(lp, lp)
+            points.append({"l": lp, "tensordot_x4_s": dt, "tensordot_x4_tflops": fl / dt / 1e12,
+                           "einsum_optimize_s": dte, "einsum_optimize_tflops": fl / dte / 1e12})
+    l, dt = (points[-1]["l"], points[-1]["tensordot_x4_s"]) if points else (48, run(48)[0])
     while dt < 0.6 * budget_s and l < l_max:  # grow the sample until it is worth 10-20 s
         nxt = int(min(l_max, max(l + 16, l * (budget_s / max(dt, 1e-3)) ** 0.2)))
         nxt -= nxt % 8
         if nxt <= l:
             break
-        l, dt = nxt, run(nxt)
+        l, dt = nxt, run(nxt)[0]
     flops = orc.transform_flops(l, l)
-    return {
+    res = {
         "value": flops / dt / 1e12, "unit": "TFLOP/s", "cores": int(threads), "kind": "port",
         "sample": f"one fp64 transform at l={l} ({flops/1e9:.1f} GFLOP, {dt:.1f} s), numpy "
                   f"{np.__version__} tensordot x4 (oracle/qs_oracle.py) on {blas} with {threads} threads "
-                  f"(os.cpu_count={os.cpu_count()})",
+                  f"(os.cpu_count={os.cpu_count()}); fixed points at l=55 and l=128 with "
+                  f"numpy.einsum(optimize=True) beside them in `points`",
+        "points": points,
     }
+    if full_l:
+        dtf, _ = run(full_l)
+        ff = orc.transform_flops(full_l, full_l)
+        res["full_size"] = {"l": full_l, "tensordot_x4_s": dtf, "tensordot_x4_tflops": ff / dtf / 1e12}
+    return res
 
 
-HBM_PEAK_GBPS = 8000.0   # MI355X_MICROARCH.md: 8 TB/s spec (6.3 TB/s measured achievable)
-
-
-def bandwidth_workload(args, torch, dist, kernels, sharded, device, rank, world, use_dist):
-    """BASELINE.json configs[3]: spatial real fp64 u at l (default 256), p-slab per rank,
-    fused spin expansion + anti-symmetrisation + complex cast to 2l spin orbitals
-    (264*l^4 algorithmic bytes), or the stand-alone anti-symmetrisation (16*l^4).  The spin
-    tensor (1.1 TB at l=256) is streamed slab by slab through one reused output buffer."""
-    l = args.l
-    part = sharded.SlabPartition(l, world)
-    p_lo, p_hi = part.bounds(rank)
-    g = torch.Generator(device=device).manual_seed(4321)
-    u = torch.empty((l, l, l, l), dtype=torch.float64, device=device)
-    for lo in range(0, l, 8):
-        u[lo:lo + 8] = torch.rand((min(8, l - lo), l, l, l), dtype=torch.float64, device=device, generator=g) - 0.5
-    if args.workload == "spin_expand":
-        rows = max(1, min(p_hi - p_lo, int(40e9 // (2 * (2 * l) ** 3 * 16))))
-        buf = torch.empty((2 * rows, 2 * l, 2 * l, 2 * l), dtype=torch.complex128, device=device)
-
-        def step():
-            for p0 in range(p_lo, p_hi, rows):
-                p1 = min(p_hi, p0 + rows)
-                kernels.spin_expand_two_body(u, antisymmetrize=True, out_dtype=torch.complex128,
-                                             p_lo=p0, p_hi=p1, out=buf[: 2 * (p1 - p0)])
-        step_bytes = (8 * l**3 + 16 * 2 * (2 * l) ** 3) * l
-        launches = -(-(p_hi - p_lo) // rows)
-        name = "fused spin-expand + antisymmetrise + complex cast"
-        kernel = "qs::spin_expand_kernel<double, f64x2>"
-    else:
-        src = u[p_lo:p_hi]
-        out = torch.empty_like(src)
-
-        def step():
-            kernels.antisymmetrize(src, out=out)
-        step_bytes = 16 * l**4
-        launches = 1
-        name = "anti-symmetrise u"
-        kernel = "qs::antisym_kernel<double>"
-
-    def barrier():
-        if use_dist:
-            dist.barrier()
-        torch.cuda.synchronize()
-
-    for _ in range(args.warmup):
-        step()
-    barrier()
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    t0 = time.perf_counter()
-    e0.record()
-    for _ in range(args.steps):
-        step()
-    e1.record()
-    barrier()
-    elapsed = time.perf_counter() - t0
-    dev_elapsed = e0.elapsed_time(e1) * 1e-3
-    if use_dist:
-        t = torch.tensor([elapsed, dev_elapsed], dtype=torch.float64, device=device)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed, dev_elapsed = t[0].item(), t[1].item()
-    # parity (value-exact): the first local p row against the definition written with torch ops
-    row = u[p_lo:p_lo + 1]
-    if args.workload == "spin_expand":
-        got = kernels.spin_expand_two_body(u, antisymmetrize=True, out_dtype=torch.complex128, p_lo=p_lo, p_hi=p_lo + 1)
-        eye = torch.eye(2, dtype=torch.float64, device=device)
-        ref = torch.einsum("pqrs,ac,bd->paqbrcsd", row, eye, eye).reshape(2, 2 * l, 2 * l, 2 * l)
-        ref = (ref - ref.transpose(2, 3)).to(torch.complex128)
-    else:
-        got = kernels.antisymmetrize(row)
-        ref = row - row.transpose(2, 3)
-    exact = bool(torch.equal(got, ref))
-    if rank == 0:
-        gbps = step_bytes * args.steps / elapsed / 1e9
-        per_launch = dev_elapsed / (args.steps * launches)
-        achieved = step_bytes / world / launches / per_launch / 1e9
-        line = {
-            "metric": f"{name} GB/s (algorithmic bytes) at l={l} spatial orbitals",
-            "value": gbps, "unit": "GB/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "strong",
-            "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": f"BASELINE.json configs[3]: spatial real fp64 u l={l} -> "
-                                   f"{2*l} spin orbitals complex128, p-slab per GPU, output streamed "
-                                   f"through a reused slab buffer" if args.workload == "spin_expand"
-                                   else f"anti-symmetrisation of real fp64 u l={l}, p-slab per GPU",
-                       "l": l, "bytes_per_step": step_bytes},
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBPS, "traffic": None, "kernel": kernel,
-                         "bytes_per_launch": step_bytes / world / launches, "avg_launch_ms": per_launch * 1e3},
-            "parity": {"value_exact_vs_definition": exact},
-        }
-        print(json.dumps(line), flush=True)
-    if use_dist:
-        dist.barrier()
-        dist.destroy_process_group()
-
+# ----------------------------------------------------------------------------------------------
+# timing helpers
+# ----------------------------------------------------------------------------------------------
 
 class _StdoutToStderr:
     """RCCL prints a version banner on STDOUT when the communicator is created; the
@@ -251,18 +316,155 @@ class _StdoutToStderr:
         os.close(self._saved)
 
 
-def main():
-    args = parse()
+def timed_steps(torch, step, steps, warmup, barrier):
+    """W untimed warm-up steps, then EXACTLY K steps bracketed by barrier + synchronize on both sides.
+    Returns (wall seconds for the K steps, device seconds between the first and last event, per-step device
+    milliseconds from HIP events recorded on the launch stream around every step, last result)."""
+    res = None
+    for i in range(warmup):
+        res = step(i)
+    barrier()
+    evs = [torch.cuda.Event(enable_timing=True) for _ in range(steps + 1)]
+    t0 = time.perf_counter()
+    evs[0].record()
+    for i in range(steps):
+        res = step(warmup + i)
+        evs[i + 1].record()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    per_step = [evs[i].elapsed_time(evs[i + 1]) for i in range(steps)]
+    return elapsed, evs[0].elapsed_time(evs[steps]) * 1e-3, per_step, res
+
+
+def median(xs):
+    s = sorted(xs)
+    n = len(s)
+    return s[n // 2] if n % 2 else 0.5 * (s[n // 2 - 1] + s[n // 2])
+
+
+def dominant_kernel(log):
+    """('name', launches per step, full dispatch text) from the per-call dispatch records of one step."""
+    counts, order = {}, []
+    for rec in log:
+        for item in rec.split(";"):
+            if not item:
+                continue
+            name, _, rep = item.partition(" x")
+            k = int(rep) if rep else 1
+            if name not in counts:
+                order.append(name)
+            counts[name] = counts.get(name, 0) + k
+    if not counts:
+        return "unknown", 1, ""
+    heavy = [n for n in order if "transpose" not in n] or order
+    total = sum(counts[n] for n in heavy)
+    text = "; ".join(f"{n} x{counts[n]}" for n in order)
+    return max(heavy, key=lambda n: counts[n]), total, text
+
+
+# ----------------------------------------------------------------------------------------------
+# HBM-bound workloads (BASELINE.json configs[3])
+# ----------------------------------------------------------------------------------------------
+
+def bandwidth_workload(args, torch, dist, kernels, sharded, device, rank, world, use_dist, ranks_seen):
+    """BASELINE.json configs[3]: spatial real fp64 u at l (default 256), p-slab per rank (generated per rank),
+    fused spin expansion + anti-symmetrisation + complex cast to 2l spin orbitals
+    (264*l^4 algorithmic bytes), or the stand-alone anti-symmetrisation (16*l^4).  The spin
+    tensor (1.1 TB at l=256) is streamed slab by slab through one reused output buffer."""
+    l = args.l
+    part = sharded.SlabPartition(l, world)
+    p_lo, p_hi = part.bounds(rank)
+    pc = p_hi - p_lo
+    u = make_u_slab(torch, l, torch.float64, device, 0, p_lo, p_hi, seed=4321, centre=True)   # rows p_lo:p_hi only
+    if args.workload == "spin_expand":
+        rows = max(1, min(pc, int(40e9 // (2 * (2 * l) ** 3 * 16))))
+        buf = torch.empty((2 * rows, 2 * l, 2 * l, 2 * l), dtype=torch.complex128, device=device)
+
+        def step(_i):
+            for r0 in range(0, pc, rows):
+                r1 = min(pc, r0 + rows)
+                kernels.spin_expand_two_body(u, antisymmetrize=True, out_dtype=torch.complex128,
+                                             p_lo=r0, p_hi=r1, out=buf[: 2 * (r1 - r0)])
+        step_bytes = (8 * l**3 + 16 * 2 * (2 * l) ** 3) * l
+        launches = -(-pc // rows)
+        name = "fused spin-expand + antisymmetrise + complex cast"
+    else:
+        out = torch.empty_like(u)
+
+        def step(_i):
+            kernels.antisymmetrize(u, out=out)
+        step_bytes = 16 * l**4
+        launches = 1
+        name = "anti-symmetrise u"
+
+    def barrier():
+        if use_dist:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    elapsed, dev_elapsed, per_step, _ = timed_steps(torch, step, args.steps, args.warmup, barrier)
+    kernels.dispatch_log = []
+    step(0)
+    kernel, _, dispatch = dominant_kernel(kernels.dispatch_log)
+    kernels.dispatch_log = None
+    if use_dist:
+        t = torch.tensor([elapsed, dev_elapsed], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed, dev_elapsed = t[0].item(), t[1].item()
+    # parity (value-exact): the first local p row against the definition written with torch ops
+    row = u[:1]
+    if args.workload == "spin_expand":
+        got = kernels.spin_expand_two_body(u, antisymmetrize=True, out_dtype=torch.complex128, p_lo=0, p_hi=1)
+        eye = torch.eye(2, dtype=torch.float64, device=device)
+        ref = torch.einsum("pqrs,ac,bd->paqbrcsd", row, eye, eye).reshape(2, 2 * l, 2 * l, 2 * l)
+        ref = (ref - ref.transpose(2, 3)).to(torch.complex128)
+    else:
+        got = kernels.antisymmetrize(row)
+        ref = row - row.transpose(2, 3)
+    ok = torch.tensor([1.0 if torch.equal(got, ref) else 0.0], dtype=torch.float64, device=device)
+    if use_dist:
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+    exact = bool(ok.item() == 1.0)
+    if rank == 0:
+        gbps = step_bytes * args.steps / elapsed / 1e9
+        per_launch = dev_elapsed / (args.steps * launches)
+        achieved = step_bytes / world / launches / per_launch / 1e9
+        line = {
+            "metric": f"{name} GB/s (algorithmic bytes) at l={l} spatial orbitals",
+            "value": gbps, "unit": "GB/s", "n_gpus": world, "n_ranks_seen": ranks_seen,
+            "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3, "ms_per_step_median": median(per_step),
+            "ms_per_step_min": min(per_step), "higher_is_better": True, "scaling": "strong",
+            "vs_baseline": None, "dtype": "f64", "data": "synthetic (p-slab generated per rank)",
+            "config": {"workload": f"BASELINE.json configs[3]: spatial real fp64 u l={l} -> "
+                                   f"{2*l} spin orbitals complex128, p-slab per GPU, output streamed "
+                                   f"through a reused slab buffer" if args.workload == "spin_expand"
+                                   else f"anti-symmetrisation of real fp64 u l={l}, p-slab per GPU",
+                       "l": l, "bytes_per_step": step_bytes},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBPS, "traffic": None, "kernel": kernel, "dispatch": dispatch,
+                         "bytes_per_launch": step_bytes / world / launches, "avg_launch_ms": per_launch * 1e3},
+            "parity": {"value_exact_vs_definition": exact},
+        }
+        print(json.dumps(line), flush=True)
+    if use_dist:
+        dist.barrier()
+        dist.destroy_process_group()
+    return 0 if exact else 3
+
+
+# ----------------------------------------------------------------------------------------------
+# one rank
+# ----------------------------------------------------------------------------------------------
+
+def run_rank(args):
     import torch
     import torch.distributed as dist
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if args.gpus != world:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch N>1 with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N")
-        args.gpus = world
+    args.gpus = world
     assert torch.cuda.is_available(), "bench.py needs a GPU (no CPU path)"
     # rehearsal hooks for a one-GPU box (never set by the driver): all ranks on cuda:0 over
     # gloo, or a one-rank RCCL group, to walk the multi-rank code paths without 8 GPUs
@@ -272,6 +474,7 @@ def main():
     torch.cuda.set_device(dev_index)
     device = torch.device("cuda", dev_index)
     use_dist = world > 1 or os.environ.get("QS_BENCH_FORCE_DIST") == "1"
+    ranks_seen = 1
     if use_dist:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -282,106 +485,159 @@ def main():
             else:
                 dist.init_process_group(backend, rank=rank, world_size=world)
             warm = torch.ones(1, dtype=torch.float64, device=device)
-            dist.all_reduce(warm)          # creates the communicator (and its banner) now
+            dist.all_reduce(warm)          # creates the communicator (and its banner) now; counts the ranks
             torch.cuda.synchronize()
+            ranks_seen = int(warm.item())
+        assert ranks_seen == dist.get_world_size() == world, (ranks_seen, dist.get_world_size(), world)
 
     from quantum_systems_amd import _lib, kernels, sharded
 
     lib = _lib.load()
     if args.workload != "transform":
-        return bandwidth_workload(args, torch, dist, kernels, sharded, device, rank, world, use_dist)
+        return bandwidth_workload(args, torch, dist, kernels, sharded, device, rank, world, use_dist, ranks_seen)
     l = args.l
     dtype = torch.float64 if args.dtype == "f64" else torch.complex128
+    es = 8 if args.dtype == "f64" else 16
     kf = 1 if args.dtype == "f64" else 4
     flops = kf * 8 * l**5
-
-    u, C, Ct = make_inputs(torch, l, dtype, device)
+    fresh_c = args.fresh_c == "on" or (args.fresh_c == "auto" and args.dtype == "c128")
     part = sharded.SlabPartition(l, world)
     p_lo, p_hi = part.bounds(rank)
 
+    layout_kind = args.layout
     if world == 1 and not use_dist:
-        out = torch.empty_like(u)
-
-        def step():
-            return kernels.transform_two_body(u, C, Ct, out=out)
-        launches_per_step = 4
-        layout = "single"
-    elif args.layout == "replicated":
-        def step():
-            o = sharded.transform_two_body_replicated(u, C, Ct, rank, world)
-            if args.gather:
-                o = sharded.all_gather_slabs(o, l, rank, world)
-            return o
-        launches_per_step = 4
-        layout = "u replicated, out p-sharded" + (", +all-gather" if args.gather else ", no collective")
-    else:
-        b_lo, b_hi = part.bounds(rank)
-        ub = u[:, b_lo:b_hi].contiguous()
-        del u
-        torch.cuda.empty_cache()
-        u = None
-
-        def step():
-            o = sharded.transform_two_body_sharded(ub, C, Ct, rank, world)
-            if args.gather:
-                o = sharded.all_gather_slabs(o, l, rank, world)
-            return o
-        launches_per_step = 3 + world
-        layout = "u b-sharded, one all-to-all, out p-sharded" + (", +all-gather" if args.gather else "")
+        layout_kind = "single" if args.layout in ("auto", "replicated") else args.layout
+    elif args.layout == "auto":
+        # replicated needs u + four slab-sized buffers per GPU
+        layout_kind = "replicated" if l**4 * es * (1 + 4 / world) < 0.85 * HBM_BYTES else "inplace"
+    if layout_kind == "inplace" and l % world:
+        raise SystemExit("--layout inplace needs l divisible by the number of GPUs")
 
     def barrier():
         if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
-    res = None
-    for _ in range(args.warmup):
-        res = step()
-    barrier()
-    ev0 = torch.cuda.Event(enable_timing=True)
-    ev1 = torch.cuda.Event(enable_timing=True)
-    t0 = time.perf_counter()
-    ev0.record()
-    for _ in range(args.steps):
-        res = step()
-    ev1.record()
-    barrier()
-    elapsed = time.perf_counter() - t0
-    dev_elapsed = ev0.elapsed_time(ev1) * 1e-3       # same stream as the kernels
+    # ---- inputs.  Coefficients: one unitary (fp64 default: a single change_basis) or a new one per step
+    n_c = (args.steps + args.warmup) if fresh_c else 1
+    Cs = [make_unitary(torch, l, dtype, device, 99 + i) for i in range(n_c)]
+    b_lo = None
+    if layout_kind in ("single", "replicated"):
+        u, C0, _ = make_inputs(torch, l, dtype, device)
+        if not fresh_c:
+            Cs = [C0]
+        data = "synthetic"
+    else:
+        b_lo, b_hi = part.bounds(rank)
+        u = make_u_slab(torch, l, dtype, device, 1, b_lo, b_hi)
+        data = "synthetic (b-slab generated per rank, not symmetrised)"
     if use_dist:
-        t = torch.tensor([elapsed, dev_elapsed], dtype=torch.float64, device=device)
+        for c in Cs:                          # QR on different devices may round differently: rank 0's C everywhere
+            cr = torch.view_as_real(c) if c.is_complex() else c
+            dist.broadcast(cr, src=0)
+    Cts = [c.conj().transpose(0, 1).resolve_conj().contiguous() for c in Cs]
+    torch.cuda.synchronize()
+
+    def coeff(i):
+        return (Cs[i % n_c], None if fresh_c else Cts[i % n_c])
+
+    full_buf = [None]
+
+    def gather(o):
+        if full_buf[0] is None:
+            full_buf[0] = torch.empty((l, l, l, l), dtype=dtype, device=device)
+        return sharded.all_gather_slabs(o, l, rank, world, full=full_buf[0])
+
+    if layout_kind == "single":
+        out = torch.empty_like(u)
+
+        def local_step(i):
+            C, Ct = coeff(i)
+            return kernels.transform_two_body(u, C, Ct, out=out)
+        layout = "single GPU"
+    elif layout_kind == "replicated":
+        def local_step(i):
+            C, Ct = coeff(i)
+            return sharded.transform_two_body_replicated(u, C, Ct, rank, world)
+        layout = "u replicated, out p-sharded, no collective on the data path"
+    elif layout_kind == "sharded":
+        def local_step(i):
+            C, Ct = coeff(i)
+            return sharded.transform_two_body_sharded(u, C, Ct, rank, world)
+        layout = "u b-sharded, one all-to-all, out p-sharded (out of place)"
+    else:
+        keep = torch.empty((l // world + 1, l, l, l), dtype=dtype, device=device)
+
+        def local_step(i):
+            C, Ct = coeff(i)
+            return sharded.transform_two_body_sharded_inplace(u, C, Ct, rank, world, staging_rows=args.staging_rows,
+                                                              out=keep)
+        layout = "u b-sharded and resident, exchange + last contraction inside the output buffer (in place)"
+
+    with_gather = args.gather and world > 1
+    step = (lambda i: gather(local_step(i))) if with_gather else local_step
+    if with_gather:
+        layout += ", + all-gather of the result"
+
+    elapsed, dev_elapsed, per_step, res = timed_steps(torch, step, args.steps, args.warmup, barrier)
+    last_i = args.warmup + args.steps - 1
+
+    # second leg at N > 1: the same steps followed by the north star's all-gather of the result
+    gather_leg = None
+    if world > 1 and not with_gather and not args.no_gather_leg and l**4 * es * (2 + 4 / world) < 0.85 * HBM_BYTES \
+            and layout_kind in ("replicated", "sharded"):
+        k2 = max(1, min(args.steps, 3))
+        e2, _, ps2, _ = timed_steps(torch, lambda i: gather(local_step(i)), k2, 1, barrier)
+        gather_leg = (e2, k2, ps2)
+        full_buf[0] = None
+
+    # which kernels ran (one extra untimed step with the dispatch record on)
+    kernels.dispatch_log = []
+    res = local_step(last_i)
+    kernel, launches_per_step, dispatch = dominant_kernel(kernels.dispatch_log)
+    kernels.dispatch_log = None
+    torch.cuda.synchronize()
+
+    if use_dist:
+        t = torch.tensor([elapsed, dev_elapsed] + ([gather_leg[0]] if gather_leg else []), dtype=torch.float64,
+                         device=device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed, dev_elapsed = t[0].item(), t[1].item()
+        if gather_leg:
+            gather_leg = (t[2].item(),) + gather_leg[1:]
+        ps = torch.tensor(per_step, dtype=torch.float64, device=device)
+        dist.all_reduce(ps, op=dist.ReduceOp.MAX)
+        per_step = ps.tolist()
 
-    # parity property at full size on this rank's rows
-    if u is not None:
-        rows = res[p_lo:p_hi] if ((world == 1 and not use_dist) or args.gather) else res
-        lhs, rhs = identity_check(torch, u, rows, C, Ct, p_lo)
-        pair = torch.stack([lhs, rhs]).to(torch.complex128)
-        if use_dist:
-            pr = torch.view_as_real(pair).contiguous()
-            dist.all_reduce(pr)
-            pair = torch.view_as_complex(pr)
-        rel = (abs(pair[0] - pair[1]) / abs(pair[1])).item()
-    else:
-        rel = None
+    # parity property at full size: partial sums of both sides on this rank, summed over the ranks
+    C_last = Cs[last_i % n_c]
+    Ct_last = Cts[last_i % n_c]
+    rows = res[p_lo:p_hi] if layout_kind == "single" else res
+    lhs, rhs = identity_parts(torch, u, rows, C_last, Ct_last, p_lo, b_lo=b_lo)
+    pair = torch.stack([lhs, rhs]).to(torch.complex128)
+    if use_dist:
+        pr = torch.view_as_real(pair).contiguous()
+        dist.all_reduce(pr)
+        pair = torch.view_as_complex(pr)
+    rel = (abs(pair[0] - pair[1]) / abs(pair[1])).item()
+    parity_ok = rel <= PARITY_BOUND
 
     if rank != 0:
         if use_dist:
             dist.barrier()
             dist.destroy_process_group()
-        return
+        return 0 if parity_ok else 3
 
     ms_per_step = elapsed / args.steps * 1e3
     value = flops * args.steps / elapsed / 1e12
-    # dominant kernel = the MFMA GEMM: `launches_per_step` launches carry all the
+    # dominant kernel = the MFMA GEMM family: `launches_per_step` launches carry all the
     # flops of a step; everything else on the stream is microseconds.
     per_launch_s = dev_elapsed / (args.steps * launches_per_step)
     achieved = (flops / world / launches_per_step) / per_launch_s / 1e12
     roofline = {
         "bound": "mfma", "achieved": achieved, "peak": MFMA_F64_PEAK_TFLOPS, "unit": "TFLOP/s",
         "frac": achieved / MFMA_F64_PEAK_TFLOPS, "traffic": None,
-        "kernel": "qs::gemm_fast_kernel<false, 4, 4, true, false> (v_mfma_f64_16x16x4_f64; exact 128x128 tiles at l = 256)",
+        "kernel": kernel, "dispatch": dispatch, "launches_per_step": launches_per_step,
         "flops_per_launch": flops / world / launches_per_step,
         "avg_launch_ms": per_launch_s * 1e3,
     }
@@ -390,7 +646,7 @@ def main():
         try:
             with open(prof) as f:
                 tr = json.load(f)
-            if tr.get("l") == l and tr.get("dtype") == args.dtype:
+            if tr.get("l") == l and tr.get("dtype") == args.dtype and tr.get("kernel", kernel) == kernel:
                 roofline["traffic"] = tr["hbm_bytes_per_launch"]
                 roofline["traffic_source"] = tr.get("source")
         except Exception:
@@ -422,29 +678,50 @@ def main():
         probes["hbm_stream_copy_tbps"] = 2 * nbytes / (e0.elapsed_time(e1) * 1e-3) / 1e12
         del src, dst
 
+    med, mn = median(per_step), min(per_step)
     line = {
         "metric": f"4-index u transform TFLOP/s ({'fp64' if kf == 1 else 'complex128'}) at L={l} orbitals",
-        "value": value, "unit": "TFLOP/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "strong",
-        "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+        "value": value, "unit": "TFLOP/s", "n_gpus": world, "n_ranks_seen": ranks_seen,
+        "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": ms_per_step, "ms_per_step_median": med, "ms_per_step_min": mn,
+        "value_at_median_step": flops / (med * 1e-3) / 1e12, "value_at_min_step": flops / (mn * 1e-3) / 1e12,
+        "higher_is_better": True, "scaling": "strong",
+        "vs_baseline": None, "dtype": args.dtype, "data": data,
         "config": {
             "workload": f"RandomBasisSet-shaped l={l} {args.dtype} four-index transform "
-                        f"(BASELINE.json configs[2]), u resident in HBM, C unitary",
+                        f"(BASELINE.json configs[{2 if kf == 1 else 4}]), u resident in HBM, C unitary"
+                        + (", a new C every step (C_tilde derived inside the call)" if fresh_c else ""),
             "l": l, "flops_per_step": flops, "layout": layout,
             "frac_of_mfma_peak": value / (MFMA_F64_PEAK_TFLOPS * world),
         },
         "roofline": roofline,
-        "parity": {"randomised_identity_rel_diff": rel, "bound": 1e-10},
+        "parity": {"randomised_identity_rel_diff": rel, "bound": PARITY_BOUND, "ok": parity_ok},
         "probes": probes,
     }
+    if world > 1:
+        line["collective"] = {"in_value": "all-gather of the result" if with_gather else (
+            "none" if layout_kind == "replicated" else "one all-to-all (re-shard of the intermediate)")}
+        if gather_leg:
+            e2, k2, _ = gather_leg
+            line["with_all_gather"] = {"value": flops * k2 / e2 / 1e12, "ms_per_step": e2 / k2 * 1e3, "steps": k2,
+                                       "note": "same steps followed by the all-gather that replicates the "
+                                               "p-sharded result on every GPU (north star's single collective)"}
     if not args.no_cpu_baseline and world == 1:   # reported at N = 1 only (rank 0 would stall the others)
-        del res
-        line["cpu_baseline"] = cpu_baseline(args.cpu_l)
+        del res, rows
+        line["cpu_baseline"] = cpu_baseline(args.cpu_l, full_l=l if args.cpu_full else None)
     print(json.dumps(line), flush=True)
     if use_dist:
         dist.barrier()
         dist.destroy_process_group()
+    return 0 if parity_ok else 3
+
+
+def main():
+    args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        return self_launch(args.gpus)
+    return run_rank(args)
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(main())

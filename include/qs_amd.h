@@ -16,6 +16,10 @@
  *   - `stream` is a hipStream_t passed as void*; all work is enqueued on it
  *     and the call returns without synchronising;
  *   - the library allocates nothing: outputs and workspace are the caller's;
+ *   - no process-global mutable state: caches are keyed by device ordinal, the
+ *     error / dispatch / tuning records are thread-local; calls are re-entrant
+ *     for distinct streams and devices (the current device must be the one
+ *     that owns the pointers and the stream);
  *   - return value: QS_OK (0) or a negative QS_ERR_* code, never throws.
  *
  * dtype codes: QS_F64 = real fp64, QS_C128 = complex128.
@@ -189,8 +193,21 @@ int qs_tdho_coulomb_elements_nm(void* out, const void* nm_table, int64_t l,
                                 void* stream);
 
 /*
- * Auxiliary entry points (no reference counterpart).
- *   qs_tuning_set: override a kernel choice for tuning runs; keys
+ * Which kernels the calling thread's most recent compute entry point launched,
+ * as the names rocprofv3 prints for them, ';'-separated, repeated launches of
+ * one instantiation folded to "name xN" (static thread-local storage; empty
+ * before the first call).  bench.py puts this string into its `roofline.kernel`
+ * field so that a bench line names the kernel that actually ran.
+ */
+const char* qs_last_dispatch(void);
+
+/*
+ * Auxiliary entry points (no reference counterpart).  NOT part of the product
+ * path: tuning runs, tests and bench probes only.
+ *   qs_tuning_set / qs_tuning_reset: override a kernel choice FOR THE CALLING
+ *     THREAD (thread-local state: the library has no process-global mutable
+ *     state; every thread starts from the automatic policy and
+ *     qs_tuning_reset() returns the calling thread to it).  Keys
  *     "gemm_f64_cfg", "gemm_c128_cfg" (tile shape of the general
  *     kernel, 0 = automatic), "gemm_pipe" (1 = rotated K-loop schedule, 0 = plain),
  *     "gemm_fast" (0 = general kernel only, 1 = automatic, 2 = exact form of
@@ -202,7 +219,8 @@ int qs_tdho_coulomb_elements_nm(void* out, const void* nm_table, int64_t l,
  *     "gemm_stream" (0 = never use the small-coefficient streaming kernel,
  *     2 = never split the rows of A over two waves), "slab_pair" (0 = never fuse
  *     the d and c contractions of a small-basis transform into one pass, 2 = one
- *     wave per slab always).
+ *     wave per slab always), "slab_ba" (0 = never fuse the b and a contractions
+ *     of a small-basis transform).
  *   qs_probe_mfma_f64: register-resident fp64 MFMA loop, `blocks` workgroups
  *     of 4 waves, each wave issuing iters*8 v_mfma_f64_16x16x4_f64
  *     (flops = blocks*4*iters*8*2048); `sink` is a device scratch of
@@ -213,6 +231,7 @@ int qs_tdho_coulomb_elements_nm(void* out, const void* nm_table, int64_t l,
  * bench.py uses the probes to print measured ceilings beside datasheet ones.
  */
 int qs_tuning_set(const char* key, int64_t value);
+int qs_tuning_reset(void);
 int qs_probe_mfma_f64(void* sink, int64_t blocks, int64_t iters, void* stream);
 int qs_probe_stream_copy(const void* src, void* dst, int64_t bytes, void* stream);
 

@@ -69,6 +69,21 @@ def transform_two_body_dcb(u, C, C_tilde=None):
     return t.transpose(0, 3, 1, 2)  # ->aqrs
 
 
+def transform_two_body_pq_samples(u, C, C_tilde, pairs):
+    """``out[p, q, :, :]`` of basis_set.py:336-350 for a few index pairs (p, q) only: O(l^4) per pair
+    instead of the O(l^5) of the whole transform, so the headline size (l = 256, 34 GB) can be checked
+    element-wise inside the default GPU suite from one download of ``u``.
+
+    The same four sums of basis_set.py:341-348, with the two bra contractions taken first because
+    their free indices are fixed:  ``W[c,d] = sum_ab Ct[p,a] Ct[q,b] u[a,b,c,d]`` (one GEMM for all the
+    pairs at once), then ``out[p,q] = C^T W C`` (:342-344).  Returns an array (len(pairs), M, M)."""
+    Ct = _bra(C, C_tilde)
+    L = u.shape[0]
+    weights = np.stack([np.multiply.outer(Ct[p], Ct[q]).reshape(L * L) for (p, q) in pairs])   # (k, (a,b))
+    W = np.dot(weights, u.reshape(L * L, L * L)).reshape(len(pairs), L, L)                     # (k, c, d)
+    return np.stack([np.dot(C.T, np.dot(w, C)) for w in W])
+
+
 def transform_two_body_einsum(u, C, C_tilde=None):
     """Five-operand einsum form the reference's tests compare against
     (tests/test_helper.py:43-51, tests/test_custom_system.py:19-24)."""

@@ -40,7 +40,9 @@ SIGNATURES = {
     "qs_spin_squared_two_body": (c_int, [c_ptr, c_ptr, c_i64, c_i64, c_i64, c_int, c_ptr]),
     "qs_tdho_coulomb_elements": (c_int, [c_ptr, c_i64, c_i64, c_i64, c_ptr]),
     "qs_tdho_coulomb_elements_nm": (c_int, [c_ptr, c_ptr, c_i64, c_i64, c_i64, c_i64, c_ptr]),
+    "qs_last_dispatch": (ctypes.c_char_p, []),
     "qs_tuning_set": (c_int, [ctypes.c_char_p, c_i64]),
+    "qs_tuning_reset": (c_int, []),
     "qs_probe_mfma_f64": (c_int, [c_ptr, c_i64, c_i64, c_ptr]),
     "qs_probe_stream_copy": (c_int, [c_ptr, c_ptr, c_i64, c_ptr]),
 }

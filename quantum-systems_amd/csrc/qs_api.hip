@@ -10,6 +10,8 @@
 // CT = C^T is materialised once (L*M elements) so that every product is the
 // same row-major kernel with the tensor streamed along its contiguous axis.
 
+#include <stdarg.h>
+#include <stdio.h>
 #include <string.h>
 
 #include "qs_common.h"
@@ -22,20 +24,91 @@ void note_hip_error(hipError_t e, const char* what) {
     snprintf(g_hip_err, sizeof(g_hip_err), "%s: %s", what, hipGetErrorString(e));
 }
 
+int current_device() {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) {
+        (void)hipGetLastError();
+        return 0;
+    }
+    return (dev >= 0 && dev < kMaxDevices) ? dev : 0;
+}
+
 int device_cu_count() {
-    static int n_cu = 0;
-    if (n_cu == 0) {
-        int dev = 0;
+    static PerDeviceInt n_cu;
+    const int dev = current_device();
+    int n = n_cu.v[dev].load(std::memory_order_relaxed);
+    if (n == 0) {
         hipDeviceProp_t prop;
-        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess &&
-            prop.multiProcessorCount > 0) {
-            n_cu = prop.multiProcessorCount;
+        if (hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) {
+            n = prop.multiProcessorCount;
         } else {
             (void)hipGetLastError();
-            n_cu = 256;   // MI355X
+            n = 256;   // MI355X
         }
+        n_cu.v[dev].store(n, std::memory_order_relaxed);
     }
-    return n_cu;
+    return n;
+}
+
+int opt_in_dynamic_lds(const void* kern, size_t lds_bytes, PerDeviceOnce& once, const char* what) {
+    if (lds_bytes <= 64 * 1024) return QS_OK;
+    const uint64_t bit = uint64_t(1) << current_device();
+    if (once.mask.load(std::memory_order_acquire) & bit) return QS_OK;
+    // a second thread racing here repeats the call, which is harmless
+    hipError_t e = hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+    if (e != hipSuccess) return hip_status(e, what);
+    once.mask.fetch_or(bit, std::memory_order_release);
+    return QS_OK;
+}
+
+int resident_workgroups(const void* kern, PerDeviceInt& cache, int fallback) {
+    const int dev = current_device();
+    int n = cache.v[dev].load(std::memory_order_relaxed);
+    if (n == 0) {
+        int nb = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kern, 256, 0) != hipSuccess || nb < 1) {
+            (void)hipGetLastError();
+            nb = fallback;
+        }
+        n = nb > 4 ? 4 : nb;
+        cache.v[dev].store(n, std::memory_order_relaxed);
+    }
+    return n;
+}
+
+thread_local Tuning g_tune;
+
+static thread_local char g_dispatch[1024] = "";
+static thread_local size_t g_dispatch_len = 0;
+
+void dispatch_reset() {
+    g_dispatch[0] = 0;
+    g_dispatch_len = 0;
+}
+
+void note_dispatch(const char* fmt, ...) {
+    char name[160];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(name, sizeof(name), fmt, ap);
+    va_end(ap);
+    // "name xN" run-length form: the four contractions of a large transform are one kernel
+    const size_t nl = strlen(name);
+    char* last = strrchr(g_dispatch, ';');
+    last = last ? last + 1 : g_dispatch;
+    if (g_dispatch_len && !strncmp(last, name, nl) && (last[nl] == 0 || !strncmp(last + nl, " x", 2))) {
+        const int count = last[nl] ? atoi(last + nl + 2) + 1 : 2;
+        const size_t room = sizeof(g_dispatch) - (size_t)(last - g_dispatch);
+        if (nl + 16 < room) {
+            snprintf(last + nl, room - nl, " x%d", count);
+            g_dispatch_len = strlen(g_dispatch);
+        }
+        return;
+    }
+    if (g_dispatch_len + nl + 2 >= sizeof(g_dispatch)) return;
+    if (g_dispatch_len) g_dispatch[g_dispatch_len++] = ';';
+    memcpy(g_dispatch + g_dispatch_len, name, nl + 1);
+    g_dispatch_len += nl;
 }
 
 static int gemm(int dtype, const void* A, const void* B, void* C, int64_t m, int64_t n, int64_t k,
@@ -101,23 +174,32 @@ const char* qs_error_string(int code) {
 
 const char* qs_last_hip_error(void) { return g_hip_err; }
 
+const char* qs_last_dispatch(void) { return g_dispatch; }
+
+int qs_tuning_reset(void) {
+    g_tune = Tuning();
+    return QS_OK;
+}
+
 int qs_tuning_set(const char* key, int64_t value) {
     if (!key) return QS_ERR_NULL_POINTER;
-    if (!strcmp(key, "gemm_f64_cfg")) { g_gemm_f64_cfg = (int)value; return QS_OK; }
-    if (!strcmp(key, "gemm_c128_cfg")) { g_gemm_c128_cfg = (int)value; return QS_OK; }
-    if (!strcmp(key, "gemm_pipe")) { g_gemm_pipe = (int)value; return QS_OK; }
-    if (!strcmp(key, "gemm_fast")) { g_gemm_fast = (int)value; return QS_OK; }
-    if (!strcmp(key, "gemm_skinny")) { g_gemm_skinny = (int)value; return QS_OK; }
-    if (!strcmp(key, "gemm_stream")) { g_gemm_stream = (int)value; return QS_OK; }
-    if (!strcmp(key, "slab_pair")) { g_slab_pair = (int)value; return QS_OK; }
-    if (!strcmp(key, "gemm_fast_persist")) { g_gemm_fast_persist = (int)value; return QS_OK; }
-    if (!strcmp(key, "gemm_fast_shape")) { g_gemm_fast_shape = (int)value; return QS_OK; }
+    if (!strcmp(key, "gemm_f64_cfg")) { g_tune.gemm_f64_cfg = (int)value; return QS_OK; }
+    if (!strcmp(key, "gemm_c128_cfg")) { g_tune.gemm_c128_cfg = (int)value; return QS_OK; }
+    if (!strcmp(key, "gemm_pipe")) { g_tune.gemm_pipe = (int)value; return QS_OK; }
+    if (!strcmp(key, "gemm_fast")) { g_tune.gemm_fast = (int)value; return QS_OK; }
+    if (!strcmp(key, "gemm_skinny")) { g_tune.gemm_skinny = (int)value; return QS_OK; }
+    if (!strcmp(key, "gemm_stream")) { g_tune.gemm_stream = (int)value; return QS_OK; }
+    if (!strcmp(key, "slab_pair")) { g_tune.slab_pair = (int)value; return QS_OK; }
+    if (!strcmp(key, "gemm_fast_persist")) { g_tune.gemm_fast_persist = (int)value; return QS_OK; }
+    if (!strcmp(key, "gemm_fast_shape")) { g_tune.gemm_fast_shape = (int)value; return QS_OK; }
+    if (!strcmp(key, "slab_ba")) { g_tune.slab_ba = (int)value; return QS_OK; }
     return QS_ERR_BAD_EXTENT;
 }
 
 int qs_matmul(int dtype, const void* A, const void* B, void* out, int64_t m, int64_t n, int64_t k,
               int64_t lda, int64_t ldb, int64_t ldc, int64_t batch, int64_t stride_a,
               int64_t stride_b, int64_t stride_c, int accumulate, void* stream) {
+    dispatch_reset();
     if (!dtype_ok(dtype)) return QS_ERR_BAD_DTYPE;
     if (!A || !B || !out) return QS_ERR_NULL_POINTER;
     const size_t es = elem_size(dtype);
@@ -137,6 +219,7 @@ int64_t qs_transform_two_body_workspace(int dtype, int64_t L, int64_t M) {
 
 int qs_transform_two_body(int dtype, const void* u, const void* C, const void* Ct, void* out,
                           void* work, int64_t work_bytes, int64_t L, int64_t M, void* stream) {
+    dispatch_reset();
     if (!dtype_ok(dtype)) return QS_ERR_BAD_DTYPE;
     if (!extents_ok(L, M)) return QS_ERR_BAD_EXTENT;
     if (!u || !C || !Ct || !out || !work) return QS_ERR_NULL_POINTER;
@@ -167,6 +250,7 @@ int64_t qs_transform_two_body_partial_workspace(int dtype, int64_t L, int64_t M,
 int qs_transform_two_body_partial(int dtype, const void* u_slab, const void* C, const void* Ct,
                                   void* v_slab, void* work, int64_t work_bytes, int64_t L,
                                   int64_t M, int64_t rows, void* stream) {
+    dispatch_reset();
     if (!dtype_ok(dtype)) return QS_ERR_BAD_DTYPE;
     if (!extents_ok(L, M) || rows <= 0 || rows > L) return QS_ERR_BAD_EXTENT;
     if (!u_slab || !C || !Ct || !v_slab || !work) return QS_ERR_NULL_POINTER;
@@ -186,6 +270,7 @@ int qs_transform_two_body_partial(int dtype, const void* u_slab, const void* C, 
 int qs_transform_one_body(int dtype, const void* h, const void* C, const void* Ct, void* out,
                           void* work, int64_t work_bytes, int64_t nmat, int64_t L, int64_t M,
                           void* stream) {
+    dispatch_reset();
     if (!dtype_ok(dtype)) return QS_ERR_BAD_DTYPE;
     if (L <= 0 || M <= 0 || nmat <= 0 || L > 65536 || M > 65536) return QS_ERR_BAD_EXTENT;
     if (!h || !C || !Ct || !out || !work) return QS_ERR_NULL_POINTER;
@@ -203,6 +288,7 @@ int qs_transform_one_body(int dtype, const void* h, const void* C, const void* C
 }
 
 int qs_antisymmetrize(int dtype, const void* u, void* out, int64_t npq, int64_t l, void* stream) {
+    dispatch_reset();
     if (!dtype_ok(dtype)) return QS_ERR_BAD_DTYPE;
     if (npq <= 0 || l <= 0 || l > 65536) return QS_ERR_BAD_EXTENT;
     if (!u || !out) return QS_ERR_NULL_POINTER;
@@ -213,6 +299,7 @@ int qs_antisymmetrize(int dtype, const void* u, void* out, int64_t npq, int64_t 
 
 int qs_spin_expand_two_body(int in_dtype, int out_dtype, const void* u, void* out, int64_t l,
                             int64_t p_lo, int64_t p_hi, int antisymmetrize_flag, void* stream) {
+    dispatch_reset();
     if (!dtype_ok(in_dtype) || !dtype_ok(out_dtype)) return QS_ERR_BAD_DTYPE;
     if (in_dtype == QS_C128 && out_dtype == QS_F64) return QS_ERR_BAD_DTYPE;
     if (l <= 0 || l > 32768 || p_lo < 0 || p_hi > l || p_lo >= p_hi) return QS_ERR_BAD_EXTENT;
@@ -225,6 +312,7 @@ int qs_spin_expand_two_body(int in_dtype, int out_dtype, const void* u, void* ou
 
 int qs_add_spin_one_body(int in_dtype, int out_dtype, const void* h, void* out, int64_t nmat,
                          int64_t l, void* stream) {
+    dispatch_reset();
     if (!dtype_ok(in_dtype) || !dtype_ok(out_dtype)) return QS_ERR_BAD_DTYPE;
     if (in_dtype == QS_C128 && out_dtype == QS_F64) return QS_ERR_BAD_DTYPE;
     if (l <= 0 || nmat <= 0 || l > (1 << 20)) return QS_ERR_BAD_EXTENT;
@@ -236,6 +324,7 @@ int qs_add_spin_one_body(int in_dtype, int out_dtype, const void* h, void* out, 
 
 int qs_spin_squared_two_body(const void* S, void* out, int64_t n, int64_t p_lo, int64_t p_hi,
                              int antisymmetrize_flag, void* stream) {
+    dispatch_reset();
     if (n <= 0 || n > 65536 || p_lo < 0 || p_hi > n || p_lo >= p_hi) return QS_ERR_BAD_EXTENT;
     if (!S || !out) return QS_ERR_NULL_POINTER;
     if (!aligned(S, 16) || !aligned(out, 16)) return QS_ERR_MISALIGNED;

@@ -4,6 +4,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <atomic>
+
 #include "qs_amd.h"
 
 namespace qs {
@@ -31,9 +33,37 @@ inline size_t elem_size(int dtype) { return dtype == QS_C128 ? 16 : 8; }
 
 inline bool dtype_ok(int dtype) { return dtype == QS_F64 || dtype == QS_C128; }
 
-// Compute units of the current device (cached: one process drives one GPU; the property query
-// costs far more than a kernel launch).
+// Library state is keyed by DEVICE, never by process: one process may drive several GPUs
+// (hipFuncSetAttribute, occupancy and the CU count are per-device facts).
+constexpr int kMaxDevices = 64;
+
+// Ordinal of the calling thread's current device (0 when the query fails).
+int current_device();
+
+// Compute units of the current device (cached per device: the property query costs far more
+// than a kernel launch).
 int device_cu_count();
+
+// "Done once on device d" flags of one kernel instantiation (bit d of the mask).
+struct PerDeviceOnce {
+    std::atomic<uint64_t> mask{0};
+};
+
+// Opt a kernel in to more than 64 KB of dynamic LDS on the current device, once per device.
+int opt_in_dynamic_lds(const void* kern, size_t lds_bytes, PerDeviceOnce& once, const char* what);
+
+// Workgroups of `kern` (256 threads, no dynamic LDS) resident per CU on the current device,
+// asked once per device and clamped to [1, 4]; `fallback` when the query fails.
+struct PerDeviceInt {
+    std::atomic<int> v[kMaxDevices];
+    PerDeviceInt() { for (auto& x : v) x.store(0); }
+};
+int resident_workgroups(const void* kern, PerDeviceInt& cache, int fallback);
+
+// Which kernels the calling thread's most recent entry point launched (qs_last_dispatch()):
+// every launcher appends the name rocprofv3 shows for its instantiation.
+void dispatch_reset();
+void note_dispatch(const char* fmt, ...) __attribute__((format(printf, 1, 2)));
 
 // ceil division for positive operands
 inline int64_t cdiv(int64_t a, int64_t b) { return (a + b - 1) / b; }
@@ -79,15 +109,21 @@ int kron_eye2(int in_dtype, int out_dtype, const void* h, void* out, int64_t nma
 int spin2_two_body(const void* S, void* out, int64_t n, int64_t p_lo, int64_t p_hi, int as,
                    hipStream_t stream);
 
-// Tuning knobs (qs_tuning_set).
-extern int g_gemm_f64_cfg;
-extern int g_gemm_c128_cfg;
-extern int g_gemm_pipe;
-extern int g_gemm_fast;
-extern int g_gemm_fast_persist;
-extern int g_gemm_fast_shape;
-extern int g_gemm_skinny;
-extern int g_gemm_stream;
-extern int g_slab_pair;
+// Tuning knobs (qs_tuning_set / qs_tuning_reset): state of the CALLING THREAD only, so a tuning
+// run or a test cannot change the dispatch of another thread's calls; every thread starts from the
+// automatic policy.
+struct Tuning {
+    int gemm_f64_cfg = 0;        // tile shape of the general kernel, 0 = automatic
+    int gemm_c128_cfg = 0;
+    int gemm_pipe = 1;           // 1: rotated K-loop schedule, 0: plain schedule (A/B reference)
+    int gemm_fast = 1;           // 0 general kernel only, 1 automatic, 2 exact form only, 3 edge form wherever legal
+    int gemm_fast_persist = 1;   // 0 one workgroup per tile, 1 automatic, 2 always persistent, >= 3 tiles per workgroup
+    int gemm_fast_shape = 0;     // forces edge-form shape 1..N (0 = by padded-work cost)
+    int gemm_skinny = 1;         // 0 disables the short-and-wide streaming product
+    int gemm_stream = 1;         // 0 disables the small-coefficient streaming product, 2 = never split rows over two waves
+    int slab_pair = 1;           // 0 disables the fused (d, c) pass, 2 = one wave per slab always
+    int slab_ba = 1;             // 0 disables the fused (b, a) pass
+};
+extern thread_local Tuning g_tune;
 
 }  // namespace qs

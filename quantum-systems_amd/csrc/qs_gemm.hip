@@ -331,9 +331,6 @@ void gemm_kernel(const GemmArgs g) {
 }
 
 // Schedule / tile-shape overrides for tuning runs (qs_tuning_set); 0 = automatic.
-int g_gemm_f64_cfg = 0;
-int g_gemm_c128_cfg = 0;
-int g_gemm_pipe = 1;     // 1: rotated K-loop schedule, 0: plain schedule (A/B reference)
 
 template <int WM, int WN, int TM, int TN, int KT, int MODE>
 static int launch_one(GemmArgs g, int64_t batch, hipStream_t stream) {
@@ -344,22 +341,18 @@ static int launch_one(GemmArgs g, int64_t batch, hipStream_t stream) {
     const int64_t nwg = (int64_t)g.tiles_m * g.tiles_n * batch;
     if (nwg <= 0 || nwg >= (int64_t(1) << 31)) return QS_ERR_BAD_EXTENT;
     const size_t lds = sizeof(double) * 2 * NP * (BM * (KT + 2) + KT * (BN + 16));
-    static bool lds_opt_in[2] = {false, false};   // per instantiation; a repeated call is harmless
+    static PerDeviceOnce lds_opt_in[2];   // per instantiation, schedule and device
     // the rotated schedule needs a second fragment set; shapes where that would
     // spill (8-byte staging with 16 accumulators, the 96x96 complex tile, the
     // 1-WG/CU tuning shapes) keep the plain schedule
     constexpr bool pipe_fits = !((MODE == MODE_F64_SCALAR && TM * TN >= 16) ||
                                  (MODE == MODE_C128 && TM * TN >= 9) || WM * WN != 4 || WM != WN);
-    const int pipe = (g_gemm_pipe && pipe_fits) ? 1 : 0;
+    const int pipe = (g_tune.gemm_pipe && pipe_fits) ? 1 : 0;
     auto kern = pipe ? gemm_kernel<WM, WN, TM, TN, KT, MODE, true>
                      : gemm_kernel<WM, WN, TM, TN, KT, MODE, false>;
-    if (lds > 64 * 1024 && !lds_opt_in[pipe]) {
-        hipError_t e = hipFuncSetAttribute((const void*)kern,
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return hip_status(e, "hipFuncSetAttribute(gemm)");
-        lds_opt_in[pipe] = true;
-    }
+    if (int rc = opt_in_dynamic_lds((const void*)kern, lds, lds_opt_in[pipe], "hipFuncSetAttribute(gemm)")) return rc;
     hipLaunchKernelGGL(kern, dim3((unsigned)nwg), dim3(64 * WM * WN), lds, stream, g);
+    note_dispatch("qs::gemm_kernel<%d, %d, %d, %d, %d, %d, %s>", WM, WN, TM, TN, KT, MODE, pipe ? "true" : "false");
     return launch_status("gemm launch");
 }
 
@@ -431,7 +424,7 @@ int gemm_f64(const double* A, const double* B, double* C, int64_t m, int64_t n, 
     // 16-byte loads need even extents/strides and 16-byte aligned bases.
     const bool vec = aligned(A, 16) && aligned(B, 16) && !(lda & 1) && !(ldb & 1) && !(k & 1) &&
                      !(n & 1) && !(sa & 1) && !(sb & 1);
-    int cfg = g_gemm_f64_cfg;
+    int cfg = g_tune.gemm_f64_cfg;
     if (cfg == 0) {
         int rc = gemm_skinny_try(QS_F64, A, B, C, m, n, k, lda, ldb, ldc, batch, accumulate, stream);
         if (rc != 1) return rc;
@@ -456,7 +449,7 @@ int gemm_c128(const double* A, const double* B, double* C, int64_t m, int64_t n,
     GemmArgs g;
     if (!fill_args(g, A, B, C, m, n, k, lda, ldb, ldc, batch, sa, sb, sc, accumulate))
         return QS_ERR_BAD_EXTENT;
-    int cfg = g_gemm_c128_cfg;
+    int cfg = g_tune.gemm_c128_cfg;
     if (cfg == 0) {
         int rc = gemm_skinny_try(QS_C128, A, B, C, m, n, k, lda, ldb, ldc, batch, accumulate, stream);
         if (rc != 1) return rc;

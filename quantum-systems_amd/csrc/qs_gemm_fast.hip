@@ -448,9 +448,6 @@ void gemm_fast_kernel(const FastArgs g) {
     }
 }
 
-int g_gemm_fast = 1;           // tuning knob: 0 general kernel only, 1 automatic, 2 exact form only, 3 edge form wherever legal
-int g_gemm_fast_persist = 1;   // tuning knob: 0 one workgroup per tile, 1 automatic, 2 always persistent
-int g_gemm_fast_shape = 0;     // tuning knob: forces edge-form shape 1..N (0 = by padded-work cost)
 
 template <bool CX, int TM, int TN, bool VEC, bool EDGE>
 static int launch_fast(const double* A, const double* B, double* C, int64_t m, int64_t n, int64_t k,
@@ -488,13 +485,13 @@ static int launch_fast(const double* A, const double* B, double* C, int64_t m, i
     //   long lists: 4 tiles per workgroup -- the dispatcher keeps balancing the grid, which a
     //   static split of a long list loses more on than the prefetch wins (-4 % at l = 256 when
     //   fully persistent, +1.5 % with 4 tiles; profiles/r01_gemm_notes.txt).
-    // g_gemm_fast_persist: 0 one tile per workgroup, 1 this policy, 2 always fully
+    // g_tune.gemm_fast_persist: 0 one tile per workgroup, 1 this policy, 2 always fully
     // persistent, >= 3 that many tiles per workgroup.
     int64_t tiles_per_wg = 1;
     bool full = false;
-    if (g_gemm_fast_persist == 1) { full = total <= 8 * P; tiles_per_wg = 4; }
-    else if (g_gemm_fast_persist == 2) full = true;
-    else if (g_gemm_fast_persist >= 3) tiles_per_wg = g_gemm_fast_persist;
+    if (g_tune.gemm_fast_persist == 1) { full = total <= 8 * P; tiles_per_wg = 4; }
+    else if (g_tune.gemm_fast_persist == 2) full = true;
+    else if (g_tune.gemm_fast_persist >= 3) tiles_per_wg = g_tune.gemm_fast_persist;
     if (!full) {
         P = (total + tiles_per_wg - 1) / tiles_per_wg;
         P = (P + 7) & ~int64_t(7);
@@ -502,13 +499,11 @@ static int launch_fast(const double* A, const double* B, double* C, int64_t m, i
     if (P > total) P = total;
     const size_t lds = sizeof(double) * 2 * NP * (BM * (KT + 2) + KT * (CX ? BN + 16 : BN));
     auto kern = gemm_fast_kernel<CX, TM, TN, VEC, EDGE>;
-    static bool lds_opt_in = false;
-    if (lds > 64 * 1024 && !lds_opt_in) {
-        hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return hip_status(e, "hipFuncSetAttribute(gemm_fast)");
-        lds_opt_in = true;
-    }
+    static PerDeviceOnce lds_opt_in;   // per instantiation and per device
+    if (int rc = opt_in_dynamic_lds((const void*)kern, lds, lds_opt_in, "hipFuncSetAttribute(gemm_fast)")) return rc;
     hipLaunchKernelGGL(kern, dim3((unsigned)P), dim3(256), lds, stream, g);
+    note_dispatch("qs::gemm_fast_kernel<%s, %d, %d, %s, %s>", CX ? "true" : "false", TM, TN, VEC ? "true" : "false",
+                  EDGE ? "true" : "false");
     return launch_status("gemm_fast launch");
 }
 
@@ -520,7 +515,7 @@ const FastShape kC128Shapes[] = {{1, 4, 2, 1.00}, {2, 2, 4, 1.00}, {3, 2, 2, 0.9
 
 template <size_t N>
 int pick_fast_shape(const FastShape (&cand)[N], int64_t m, int64_t n) {
-    if (g_gemm_fast_shape >= 1 && g_gemm_fast_shape <= (int)N) return g_gemm_fast_shape;
+    if (g_tune.gemm_fast_shape >= 1 && g_tune.gemm_fast_shape <= (int)N) return g_tune.gemm_fast_shape;
     int best = cand[0].id;
     double best_cost = 1e300;
     for (const FastShape& c : cand) {
@@ -537,7 +532,7 @@ int pick_fast_shape(const FastShape (&cand)[N], int64_t m, int64_t n) {
 int gemm_fast_try(int dtype, const double* A, const double* B, double* C, int64_t m, int64_t n,
                   int64_t k, int64_t lda, int64_t ldb, int64_t ldc, int64_t batch, int64_t sa,
                   int64_t sb, int64_t sc, int accumulate, int group_along_m, hipStream_t stream) {
-    if (!g_gemm_fast) return 1;
+    if (!g_tune.gemm_fast) return 1;
     const bool cx = dtype == QS_C128;
     const int64_t esz = cx ? 16 : 8;
     if (cx && (!aligned(A, 16) || !aligned(B, 16) || !aligned(C, 16))) return 1;
@@ -565,9 +560,9 @@ int gemm_fast_try(int dtype, const double* A, const double* B, double* C, int64_
     // +3...9 % for fp64 products whose m and n are both >= 100 (l = 100, 160, 192, 200), slower
     // below that (short tile lists: the general kernel's small and 96-wide shapes win) and for
     // complex128 (whose general kernel is already light on VALU work per MFMA).
-    // g_gemm_fast: 1 = that policy, 3 = edge form wherever it applies (tests, tuning).
-    if (g_gemm_fast != 1 && g_gemm_fast != 3) return 1;
-    if (g_gemm_fast == 1 && (cx || m < 100 || n < 100)) return 1;
+    // g_tune.gemm_fast: 1 = that policy, 3 = edge form wherever it applies (tests, tuning).
+    if (g_tune.gemm_fast != 1 && g_tune.gemm_fast != 3) return 1;
+    if (g_tune.gemm_fast == 1 && (cx || m < 100 || n < 100)) return 1;
     if (cx) {
         switch (pick_fast_shape(kC128Shapes, m, n)) {
             case 1: QS_FAST(true, 4, 2, true, true);

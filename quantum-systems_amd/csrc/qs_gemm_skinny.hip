@@ -168,23 +168,19 @@ static int launch_skinny(const double* A, const double* B, double* C, int64_t n,
     if (nwg <= 0 || nwg >= (int64_t(1) << 31)) return QS_ERR_BAD_EXTENT;
     const size_t lds = sizeof(double) * NP * M * (k + 2);
     auto kern = gemm_skinny_kernel<CX, TMS>;
-    static bool lds_opt_in = false;
-    if (lds > 64 * 1024 && !lds_opt_in) {
-        hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return hip_status(e, "hipFuncSetAttribute(gemm_skinny)");
-        lds_opt_in = true;
-    }
+    static PerDeviceOnce lds_opt_in;
+    if (int rc = opt_in_dynamic_lds((const void*)kern, lds, lds_opt_in, "hipFuncSetAttribute(gemm_skinny)")) return rc;
     hipLaunchKernelGGL(kern, dim3((unsigned)nwg), dim3(256), lds, stream, g);
+    note_dispatch("qs::gemm_skinny_kernel<%s, %d>", CX ? "true" : "false", TMS);
     return launch_status("gemm_skinny launch");
 }
 
-int g_gemm_skinny = 1;   // tuning knob: 0 disables this path
 
 // QS_OK / error after launching, 1 = not eligible (caller falls back).
 int gemm_skinny_try(int dtype, const double* A, const double* B, double* C, int64_t m, int64_t n,
                     int64_t k, int64_t lda, int64_t ldb, int64_t ldc, int64_t batch, int accumulate,
                     hipStream_t stream) {
-    if (!g_gemm_skinny || batch != 1 || accumulate) return 1;
+    if (!g_tune.gemm_skinny || batch != 1 || accumulate) return 1;
     const bool cx = dtype == QS_C128;
     // m = 64 is MFMA-bound (16 flop/B) and runs better on the tiled kernel (9.8 vs 15.3 ms at
     // l = 256); the streaming form is used where the product is HBM-bound: m <= 32 rows

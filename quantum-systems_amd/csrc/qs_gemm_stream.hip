@@ -328,7 +328,6 @@ void gemm_stream_left_cx_kernel(const StreamArgs g) {
     }
 }
 
-int g_gemm_stream = 1;   // tuning knob: 0 disables this path, 2 = never split the rows over two waves
 
 template <int TMW, int SPLIT, int KQ, bool VEC>
 static int launch_stream(const StreamArgs& g0, int64_t batch, hipStream_t stream) {
@@ -342,19 +341,13 @@ static int launch_stream(const StreamArgs& g0, int64_t batch, hipStream_t stream
     const int n_cu = device_cu_count();
     // persistent waves: every wave (pair) walks blocks w, w + W, ...; as many workgroups per CU as the
     // kernel's registers admit (asked once per instantiation)
-    static int wg_per_cu = 0;
-    if (wg_per_cu == 0) {
-        int nb = 0;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, gemm_stream_left_kernel<TMW, SPLIT, KQ, NT, VEC>, 256, 0) !=
-                hipSuccess || nb < 1) {
-            (void)hipGetLastError();
-            nb = (TMW * KQ > 8) ? 1 : 2;
-        }
-        wg_per_cu = nb > 4 ? 4 : nb;
-    }
+    static PerDeviceInt occupancy;
+    const int wg_per_cu = resident_workgroups((const void*)gemm_stream_left_kernel<TMW, SPLIT, KQ, NT, VEC>, occupancy,
+                                              (TMW * KQ > 8) ? 1 : 2);
     int64_t wgs = cdiv(total * SPLIT, 4);
     if (wgs > (int64_t)wg_per_cu * n_cu) wgs = (int64_t)wg_per_cu * n_cu;
     hipLaunchKernelGGL((gemm_stream_left_kernel<TMW, SPLIT, KQ, NT, VEC>), dim3((unsigned)wgs), dim3(256), 0, stream, g);
+    note_dispatch("qs::gemm_stream_left_kernel<%d, %d, %d, %d, %s>", TMW, SPLIT, KQ, NT, VEC ? "true" : "false");
     return launch_status("gemm_stream launch");
 }
 
@@ -367,19 +360,13 @@ static int launch_stream_cx(const StreamArgs& g0, int64_t batch, hipStream_t str
     g.blocks_per_batch = (unsigned)bpb;
     g.total_blocks = (unsigned)total;
     const int n_cu = device_cu_count();
-    static int wg_per_cu = 0;
-    if (wg_per_cu == 0) {
-        int nb = 0;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, gemm_stream_left_cx_kernel<TMW, SPLIT, KQ>, 256, 0) !=
-                hipSuccess || nb < 1) {
-            (void)hipGetLastError();
-            nb = (TMW * KQ > 3) ? 1 : 2;
-        }
-        wg_per_cu = nb > 4 ? 4 : nb;
-    }
+    static PerDeviceInt occupancy;
+    const int wg_per_cu = resident_workgroups((const void*)gemm_stream_left_cx_kernel<TMW, SPLIT, KQ>, occupancy,
+                                              (TMW * KQ > 3) ? 1 : 2);
     int64_t wgs = cdiv(total * SPLIT, 4);
     if (wgs > (int64_t)wg_per_cu * n_cu) wgs = (int64_t)wg_per_cu * n_cu;
     hipLaunchKernelGGL((gemm_stream_left_cx_kernel<TMW, SPLIT, KQ>), dim3((unsigned)wgs), dim3(256), 0, stream, g);
+    note_dispatch("qs::gemm_stream_left_cx_kernel<%d, %d, %d>", TMW, SPLIT, KQ);
     return launch_status("gemm_stream_cx launch");
 }
 
@@ -387,7 +374,7 @@ static int launch_stream_cx(const StreamArgs& g0, int64_t batch, hipStream_t str
 int gemm_stream_try(int dtype, const double* A, const double* B, double* C, int64_t m, int64_t n,
                     int64_t k, int64_t lda, int64_t ldb, int64_t ldc, int64_t batch, int64_t sa,
                     int64_t sb, int64_t sc, int accumulate, hipStream_t stream) {
-    if (!g_gemm_stream || accumulate) return 1;
+    if (!g_tune.gemm_stream || accumulate) return 1;
     if (dtype != QS_F64 && dtype != QS_C128) return 1;
     const bool cx = dtype == QS_C128;
     const int64_t esz = cx ? 16 : 8;
@@ -428,7 +415,7 @@ int gemm_stream_try(int dtype, const double* A, const double* B, double* C, int6
     }
     const bool vec = aligned(B, 16) && aligned(C, 16) && !(ldb & 1) && !(ldc & 1) && !(sb & 1) &&
                      !(sc & 1) && !(n & 1);
-    const bool split = tm > 2 && g_gemm_stream != 2;
+    const bool split = tm > 2 && g_tune.gemm_stream != 2;
 #define QS_STREAM_KQ(TMWV, SPLITV)                                                                         \
     switch (kq) {                                                                                          \
         case 1: return vec ? launch_stream<TMWV, SPLITV, 1, true>(g, batch, stream) : launch_stream<TMWV, SPLITV, 1, false>(g, batch, stream); \

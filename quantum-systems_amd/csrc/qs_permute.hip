@@ -45,7 +45,7 @@ __device__ __forceinline__ void tile_pair(int idx, int nt, int& ti, int& tj) {
 
 // Load a PT x PT tile of the l x l matrix `m` (row r0.., col c0..) into LDS.
 template <typename T>
-__device__ __forceinline__ void load_tile(T (*t)[PS], const T* __restrict__ m, int l, int r0, int c0) {
+__device__ __forceinline__ void load_tile(T (*t)[PS], const T* m, int l, int r0, int c0) {
     const int tx = threadIdx.x & (PT - 1), ty = threadIdx.x / PT;   // 256 threads: ty in 0..7
 #pragma unroll
     for (int rr = ty; rr < PT; rr += 8) {
@@ -57,9 +57,10 @@ __device__ __forceinline__ void load_tile(T (*t)[PS], const T* __restrict__ m, i
 // ----------------------------------------------------------------------------
 // out[pq][r][s] = u[pq][r][s] - u[pq][s][r]         (basis_set.py:776-778)
 // ----------------------------------------------------------------------------
+// `out` may be `u` itself (in-place form): a workgroup owns a tile and its mirror tile, reads both
+// into LDS, and only stores after the barrier -- so the pointers carry no __restrict__.
 template <typename T>
-__global__ __launch_bounds__(256) void antisym_kernel(const T* __restrict__ u, T* __restrict__ out,
-                                                      int l, int nt, int npairs) {
+__global__ __launch_bounds__(256) void antisym_kernel(const T* u, T* out, int l, int nt, int npairs) {
     __shared__ T t1[PT][PS];
     __shared__ T t2[PT][PS];
     const int64_t pq = blockIdx.x / npairs;
@@ -248,6 +249,7 @@ int antisymmetrize(int dtype, const void* u, void* out, int64_t npq, int64_t l, 
     else
         hipLaunchKernelGGL(antisym_kernel<f64x2>, dim3((unsigned)nwg), dim3(256), 0, stream,
                            (const f64x2*)u, (f64x2*)out, (int)l, nt, (int)npairs);
+    note_dispatch("qs::antisym_kernel<%s>", dtype == QS_F64 ? "double" : "f64x2");
     return launch_status("antisymmetrize launch");
 }
 
@@ -269,6 +271,8 @@ int spin_expand(int in_dtype, int out_dtype, const void* u, void* out, int64_t l
                            (const f64x2*)u, (f64x2*)out, (int)l, nt, (int)npairs, (int)p_lo, as);
     else
         return QS_ERR_BAD_DTYPE;
+    note_dispatch("qs::spin_expand_kernel<%s, %s>", in_dtype == QS_F64 ? "double" : "f64x2",
+                  out_dtype == QS_F64 ? "double" : "f64x2");
     return launch_status("spin_expand launch");
 }
 
@@ -286,6 +290,7 @@ int kron_eye2(int in_dtype, int out_dtype, const void* h, void* out, int64_t nma
                            (const f64x2*)h, (f64x2*)out, nmat, (int)l);
     else
         return QS_ERR_BAD_DTYPE;
+    note_dispatch("qs::kron_eye2_kernel");
     return launch_status("kron_eye2 launch");
 }
 
@@ -294,10 +299,14 @@ int spin2_two_body(const void* S, void* out, int64_t n, int64_t p_lo, int64_t p_
     const int rchunks = (int)cdiv(n, 8);
     const int64_t nwg = (p_hi - p_lo) * n * rchunks;
     if (nwg >= (int64_t(1) << 31)) return QS_ERR_BAD_EXTENT;
-    const size_t lds = sizeof(double) * 2 * 6 * n;
-    if (lds > 64 * 1024) return QS_ERR_BAD_EXTENT;
+    const size_t lds = sizeof(double) * 2 * 6 * n;       // rows p and q of S_x, S_y, S_z: 96 n bytes
+    if (lds > 160 * 1024) return QS_ERR_BAD_EXTENT;      // n <= 1706 spin orbitals (LDS of one CU)
+    static PerDeviceOnce lds_opt_in;                     // beyond 64 KB (n > 682) the kernel opts in, per device
+    if (int rc = opt_in_dynamic_lds((const void*)spin2_tb_kernel, lds, lds_opt_in, "hipFuncSetAttribute(spin2_tb)"))
+        return rc;
     hipLaunchKernelGGL(spin2_tb_kernel, dim3((unsigned)nwg), dim3(256), lds, stream,
                        (const f64x2*)S, (f64x2*)out, (int)n, (int)p_lo, rchunks, as);
+    note_dispatch("qs::spin2_tb_kernel");
     return launch_status("spin2_two_body launch");
 }
 

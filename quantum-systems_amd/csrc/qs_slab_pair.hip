@@ -303,31 +303,32 @@ void slab_pair_split_kernel(const SlabArgs g) {
     }
 }
 
-int g_slab_pair = 1;   // tuning knob: 0 disables the fused (d, c) pass, 2 = one wave per slab always
 
 template <int TL, int TM>
 static int launch_slab_pair(const SlabArgs& g, hipStream_t stream) {
     const int n_cu = device_cu_count();
     const size_t lds = sizeof(double) * (4 * TL) * TM * 64;
     if constexpr (TM % 2 == 0) {
-        if (g_slab_pair != 2) {
+        if (g_tune.slab_pair != 2) {
             // two waves per slab, two workgroups (four slabs in flight) per CU
             int64_t wgs = cdiv(g.nslabs, 2);
             if (wgs > 2 * (int64_t)n_cu) wgs = 2 * (int64_t)n_cu;
             hipLaunchKernelGGL((slab_pair_split_kernel<TL, TM>), dim3((unsigned)wgs), dim3(256), lds, stream, g);
+            note_dispatch("qs::slab_pair_split_kernel<%d, %d>", TL, TM);
             return launch_status("slab_pair_split launch");
         }
     }
     int64_t wgs = cdiv(g.nslabs, 4);
     if (wgs > n_cu) wgs = n_cu;                       // one wave per SIMD, persistent
     hipLaunchKernelGGL((slab_pair_kernel<TL, TM>), dim3((unsigned)wgs), dim3(256), lds, stream, g);
+    note_dispatch("qs::slab_pair_kernel<%d, %d>", TL, TM);
     return launch_status("slab_pair launch");
 }
 
 // Z[s] = B^T . X[s] . B for s < nslabs; QS_OK / error after launching, 1 = not eligible.
 int slab_pair_try(int dtype, const void* X, const void* B, void* Z, int64_t nslabs, int64_t L, int64_t M,
                   hipStream_t stream) {
-    if (!g_slab_pair || dtype != QS_F64) return 1;
+    if (!g_tune.slab_pair || dtype != QS_F64) return 1;
     if (L < 1 || M < 1 || L > 64 || M > 64) return 1;
     if (nslabs < 256 || nslabs >= (int64_t(1) << 31)) return 1;    // enough slabs to occupy the waves
     SlabArgs g;

@@ -27,6 +27,17 @@ def _stream():
     return torch.cuda.current_stream().cuda_stream
 
 
+# Measurement hook (bench.py): when this is a list, every compute call appends the kernels it
+# launched (qs_last_dispatch), so a bench line can name what actually ran.  None = off.
+dispatch_log = None
+
+
+def _ran(code, what):
+    check(code, what)
+    if dispatch_log is not None:
+        dispatch_log.append(_lib.load().qs_last_dispatch().decode())
+
+
 def _dev(t, dtype=None):
     """Contiguous, conjugation-resolved device tensor of the wanted dtype."""
     if not isinstance(t, torch.Tensor):
@@ -39,6 +50,43 @@ def _dev(t, dtype=None):
     if dtype is not None and t.dtype != dtype:
         t = t.to(dtype)
     return t.resolve_conj().contiguous()
+
+
+class _on_device_of:
+    """Launch context: makes the device that owns the operands current (the C ABI
+    launches on the current device, and ``_stream()`` is that device's current
+    stream) and refuses operands that live on different devices."""
+
+    def __init__(self, *tensors):
+        devs = {t.device for t in tensors if t is not None}
+        if len(devs) != 1:
+            raise ValueError(f"operands live on different devices: {sorted(str(d) for d in devs)}")
+        self.device = devs.pop()
+        self._guard = None
+
+    def __enter__(self):
+        if self.device.index != torch.cuda.current_device():
+            self._guard = torch.cuda.device(self.device)
+            self._guard.__enter__()
+        return self
+
+    def __exit__(self, *exc):
+        if self._guard is not None:
+            self._guard.__exit__(*exc)
+        return False
+
+
+def _check_out(out, shape, dt, what):
+    """A caller-supplied output buffer goes to the kernels as a raw pointer: it
+    must be exactly what the kernel will write (dtype, shape, contiguous, on the GPU)."""
+    if not isinstance(out, torch.Tensor) or not out.is_cuda:
+        raise ValueError(f"{what}: `out` must be a device tensor")
+    if out.dtype != dt or tuple(out.shape) != tuple(shape) or not out.is_contiguous():
+        raise ValueError(
+            f"{what}: `out` must be a contiguous {dt} tensor of shape {tuple(shape)}, got "
+            f"{out.dtype} {tuple(out.shape)}{'' if out.is_contiguous() else ' (non-contiguous)'}"
+        )
+    return out
 
 
 def result_dtype(*tensors):
@@ -96,14 +144,15 @@ def gemm_raw(dt, A, B, out, m, n, k, lda, ldb, ldc, batch=1, sa=0, sb=0, sc=0,
     (contiguous storage, matching dtype); offsets and strides in elements."""
     lib = _lib.load()
     es = 16 if dt == _C128 else 8
-    check(
-        lib.qs_matmul(
-            dtype_code(dt), A.data_ptr() + a_off * es, B.data_ptr() + b_off * es,
-            out.data_ptr() + c_off * es, m, n, k, lda, ldb, ldc, batch, sa, sb, sc,
-            1 if accumulate else 0, _stream(),
-        ),
-        "qs_matmul",
-    )
+    with _on_device_of(A, B, out):
+        _ran(
+            lib.qs_matmul(
+                dtype_code(dt), A.data_ptr() + a_off * es, B.data_ptr() + b_off * es,
+                out.data_ptr() + c_off * es, m, n, k, lda, ldb, ldc, batch, sa, sb, sc,
+                1 if accumulate else 0, _stream(),
+            ),
+            "qs_matmul",
+        )
     return out
 
 
@@ -130,7 +179,8 @@ def matmul(A, B, out=None, accumulate=False):
         if accumulate:
             raise ValueError("accumulate needs an output buffer")
         out = torch.empty(oshape, dtype=dt, device=A.device)
-    elif out.dtype != dt or out.numel() != batch * m * n or not out.is_contiguous():
+    elif (not isinstance(out, torch.Tensor) or not out.is_cuda or out.dtype != dt
+          or out.numel() != batch * m * n or not out.is_contiguous()):
         raise ValueError("bad output buffer")
     return gemm_raw(dt, A, B, out, m, n, k, k, n, n, batch, 0, k * n, m * n, accumulate)
 
@@ -153,14 +203,17 @@ def transform_two_body(u, C, C_tilde=None, out=None):
     nbytes = check(lib.qs_transform_two_body_workspace(code, L, M), "workspace query")
     if out is None:
         out = torch.empty((M, M, M, M), dtype=dt, device=u.device)
-    work = workspace.get(nbytes, u.device)
-    check(
-        lib.qs_transform_two_body(
-            code, u.data_ptr(), C.data_ptr(), Ct.data_ptr(), out.data_ptr(),
-            work.data_ptr(), work.numel(), L, M, _stream(),
-        ),
-        "qs_transform_two_body",
-    )
+    else:
+        _check_out(out, (M, M, M, M), dt, "transform_two_body")
+    with _on_device_of(u, C, Ct, out):
+        work = workspace.get(nbytes, u.device)
+        _ran(
+            lib.qs_transform_two_body(
+                code, u.data_ptr(), C.data_ptr(), Ct.data_ptr(), out.data_ptr(),
+                work.data_ptr(), work.numel(), L, M, _stream(),
+            ),
+            "qs_transform_two_body",
+        )
     return out
 
 
@@ -199,13 +252,16 @@ class TransformPlan:
         self._work = torch.empty(int(nbytes), dtype=torch.uint8, device=self.u.device)
 
         def launch():
-            check(
+            _ran(
                 lib.qs_transform_two_body(
                     code, self.u.data_ptr(), self.C.data_ptr(), self.C_tilde.data_ptr(),
                     self.out.data_ptr(), self._work.data_ptr(), self._work.numel(), L, M, _stream(),
                 ),
                 "qs_transform_two_body",
             )
+
+        if self.u.device.index != torch.cuda.current_device():
+            raise ValueError("TransformPlan: make the device that owns `u` current first (torch.cuda.device)")
 
         # one eager run on a side stream (first-launch set-up: function attributes, device
         # properties), then the capture
@@ -243,14 +299,17 @@ def transform_two_body_partial(u_slab, C, C_tilde=None, out=None):
     )
     if out is None:
         out = torch.empty((rows, M, M, M), dtype=dt, device=u_slab.device)
-    work = workspace.get(nbytes, u_slab.device)
-    check(
-        lib.qs_transform_two_body_partial(
-            code, u_slab.data_ptr(), C.data_ptr(), Ct.data_ptr(), out.data_ptr(),
-            work.data_ptr(), work.numel(), L, M, rows, _stream(),
-        ),
-        "qs_transform_two_body_partial",
-    )
+    else:
+        _check_out(out, (rows, M, M, M), dt, "transform_two_body_partial")
+    with _on_device_of(u_slab, C, Ct, out):
+        work = workspace.get(nbytes, u_slab.device)
+        _ran(
+            lib.qs_transform_two_body_partial(
+                code, u_slab.data_ptr(), C.data_ptr(), Ct.data_ptr(), out.data_ptr(),
+                work.data_ptr(), work.numel(), L, M, rows, _stream(),
+            ),
+            "qs_transform_two_body_partial",
+        )
     return out
 
 
@@ -272,14 +331,15 @@ def transform_one_body(h, C, C_tilde=None):
     nmat = hs.shape[0]
     out = torch.empty((nmat, M, M), dtype=dt, device=h.device)
     es = 16 if dt == _C128 else 8
-    work = workspace.get(nmat * L * M * es, h.device)
-    check(
-        lib.qs_transform_one_body(
-            dtype_code(dt), hs.data_ptr(), C.data_ptr(), Ct.data_ptr(), out.data_ptr(),
-            work.data_ptr(), work.numel(), nmat, L, M, _stream(),
-        ),
-        "qs_transform_one_body",
-    )
+    with _on_device_of(hs, C, Ct):
+        work = workspace.get(nmat * L * M * es, h.device)
+        _ran(
+            lib.qs_transform_one_body(
+                dtype_code(dt), hs.data_ptr(), C.data_ptr(), Ct.data_ptr(), out.data_ptr(),
+                work.data_ptr(), work.numel(), nmat, L, M, _stream(),
+            ),
+            "qs_transform_one_body",
+        )
     return out[0] if single else out.reshape(*h.shape[:-2], M, M)
 
 
@@ -298,12 +358,13 @@ def antisymmetrize(u, out=None):
         out = torch.empty_like(src)
     elif in_place:
         out = src          # the kernel's tile-pair scheme is safe in place
-    elif out.dtype != dt or tuple(out.shape) != tuple(src.shape) or not out.is_contiguous():
-        raise ValueError("bad output buffer")
-    check(
-        lib.qs_antisymmetrize(dtype_code(dt), src.data_ptr(), out.data_ptr(), npq, l, _stream()),
-        "qs_antisymmetrize",
-    )
+    else:
+        _check_out(out, src.shape, dt, "antisymmetrize")
+    with _on_device_of(src, out):
+        _ran(
+            lib.qs_antisymmetrize(dtype_code(dt), src.data_ptr(), out.data_ptr(), npq, l, _stream()),
+            "qs_antisymmetrize",
+        )
     if in_place and src is not u:
         u.copy_(src)       # `u` was a view / other dtype: write the result back into it
         return u
@@ -313,27 +374,37 @@ def antisymmetrize(u, out=None):
 def spin_expand_two_body(u, antisymmetrize=False, out_dtype=None, p_lo=0, p_hi=None, out=None):
     """Spin doubling of (l,l,l,l) -> rows [2 p_lo, 2 p_hi) of (2l,2l,2l,2l)
     (basis_set.py:772-774), optionally fused with the anti-symmetrisation
-    (:776-778) and the complex cast (:634)."""
+    (:776-778) and the complex cast (:634).
+
+    ``u`` may also be a leading-index slab ``u[a:b]`` of shape (rows,l,l,l) -- the
+    p-sharded layout, where no rank holds the whole tensor; ``p_lo``/``p_hi`` then
+    count rows of the slab (the expansion is slab-local: output row 2p+s needs
+    input row p only)."""
     lib = _lib.load()
     dt = result_dtype(u)
     u = _dev(u, dt)
-    l = u.shape[0]
-    if tuple(u.shape) != (l, l, l, l):
+    if u.dim() != 4:
         raise ValueError("u must be (l,l,l,l)")
-    p_hi = l if p_hi is None else p_hi
+    rows, l = u.shape[0], u.shape[-1]
+    if tuple(u.shape[1:]) != (l, l, l) or rows > l or rows < 1:
+        raise ValueError("u must be (l,l,l,l) or a leading-index slab (rows,l,l,l)")
+    p_hi = rows if p_hi is None else p_hi
+    if not 0 <= p_lo < p_hi <= rows:
+        raise ValueError(f"rows [{p_lo}, {p_hi}) are not inside the {rows} rows of u")
     odt = dt if out_dtype is None else out_dtype
     shape = (2 * (p_hi - p_lo), 2 * l, 2 * l, 2 * l)
     if out is None:
         out = torch.empty(shape, dtype=odt, device=u.device)
-    elif tuple(out.shape) != shape or out.dtype != odt or not out.is_contiguous():
-        raise ValueError("bad output buffer")
-    check(
-        lib.qs_spin_expand_two_body(
-            dtype_code(dt), dtype_code(odt), u.data_ptr(), out.data_ptr(), l, p_lo, p_hi,
-            1 if antisymmetrize else 0, _stream(),
-        ),
-        "qs_spin_expand_two_body",
-    )
+    else:
+        _check_out(out, shape, odt, "spin_expand_two_body")
+    with _on_device_of(u, out):
+        _ran(
+            lib.qs_spin_expand_two_body(
+                dtype_code(dt), dtype_code(odt), u.data_ptr(), out.data_ptr(), l, p_lo, p_hi,
+                1 if antisymmetrize else 0, _stream(),
+            ),
+            "qs_spin_expand_two_body",
+        )
     return out
 
 
@@ -348,12 +419,13 @@ def add_spin_one_body(h, out_dtype=None):
     nmat = h.numel() // (l * l)
     odt = dt if out_dtype is None else out_dtype
     out = torch.empty(tuple(h.shape[:-2]) + (2 * l, 2 * l), dtype=odt, device=h.device)
-    check(
-        lib.qs_add_spin_one_body(
-            dtype_code(dt), dtype_code(odt), h.data_ptr(), out.data_ptr(), nmat, l, _stream()
-        ),
-        "qs_add_spin_one_body",
-    )
+    with _on_device_of(h):
+        _ran(
+            lib.qs_add_spin_one_body(
+                dtype_code(dt), dtype_code(odt), h.data_ptr(), out.data_ptr(), nmat, l, _stream()
+            ),
+            "qs_add_spin_one_body",
+        )
     return out
 
 
@@ -367,12 +439,13 @@ def spin_squared_two_body(S, antisymmetrize=False, p_lo=0, p_hi=None):
         raise ValueError("S must be (3,n,n)")
     p_hi = n if p_hi is None else p_hi
     out = torch.empty((p_hi - p_lo, n, n, n), dtype=_C128, device=S.device)
-    check(
-        lib.qs_spin_squared_two_body(
-            S.data_ptr(), out.data_ptr(), n, p_lo, p_hi, 1 if antisymmetrize else 0, _stream()
-        ),
-        "qs_spin_squared_two_body",
-    )
+    with _on_device_of(S):
+        _ran(
+            lib.qs_spin_squared_two_body(
+                S.data_ptr(), out.data_ptr(), n, p_lo, p_hi, 1 if antisymmetrize else 0, _stream()
+            ),
+            "qs_spin_squared_two_body",
+        )
     return out
 
 
@@ -410,4 +483,33 @@ def antisymmetrize_(u):
 
 
 def tuning_set(key, value):
+    """Tuning / test hook: kernel-choice override for the CALLING THREAD only
+    (the library keeps no process-global mutable state)."""
     check(_lib.load().qs_tuning_set(key.encode(), int(value)), "qs_tuning_set")
+
+
+def tuning_reset():
+    """Back to the automatic kernel choice on the calling thread."""
+    check(_lib.load().qs_tuning_reset(), "qs_tuning_reset")
+
+
+class tuning:
+    """``with tuning(gemm_fast=0): ...`` -- overrides for the block, automatic policy after it."""
+
+    def __init__(self, **knobs):
+        self.knobs = knobs
+
+    def __enter__(self):
+        for key, value in self.knobs.items():
+            tuning_set(key, value)
+        return self
+
+    def __exit__(self, *exc):
+        tuning_reset()
+        return False
+
+
+def last_dispatch():
+    """Names (as rocprofv3 prints them) of the kernels the calling thread's most
+    recent library call launched, e.g. ``qs::gemm_fast_kernel<false, 4, 4, true, false> x4``."""
+    return _lib.load().qs_last_dispatch().decode()

@@ -105,22 +105,28 @@ def _as_real_flat(t):
     return t.reshape(-1)
 
 
-def all_gather_slabs(out_slab, M, rank, world, group=None):
-    """Replicate the p-sharded result: returns the full (M,M,M,M) tensor.
-    One all-gather over the node (uneven slabs are padded to the largest)."""
+def all_gather_slabs(out_slab, M, rank, world, group=None, full=None):
+    """Replicate the p-sharded result: returns the full (M,M,M,M) tensor (the single
+    all-gather of the north star).  Even slabs are gathered straight into the result
+    tensor (no staging copy); uneven slabs are padded to the largest.  ``full`` may
+    supply the result buffer."""
     part = SlabPartition(M, world)
     if world == 1:
         return out_slab
     per_row = M * M * M
     width = 2 if out_slab.is_complex() else 1
+    if full is None:
+        full = torch.empty((M, M, M, M), dtype=out_slab.dtype, device=out_slab.device)
+    full_flat = _as_real_flat(full)  # view of `full`
+    flat = _as_real_flat(out_slab)
+    if M % world == 0:
+        dist.all_gather_into_tensor(full_flat, flat, group=group)
+        return full
     biggest = max(part.count(r) for r in range(world)) * per_row * width
     send = torch.zeros(biggest, dtype=torch.float64, device=out_slab.device)
-    flat = _as_real_flat(out_slab)
     send[: flat.numel()] = flat
     recv = torch.empty(world * biggest, dtype=torch.float64, device=out_slab.device)
     dist.all_gather_into_tensor(recv, send, group=group)
-    full = torch.empty((M, M, M, M), dtype=out_slab.dtype, device=out_slab.device)
-    full_flat = _as_real_flat(full)  # view of `full`
     for r in range(world):
         lo, hi = part.bounds(r)
         n = (hi - lo) * per_row * width
@@ -196,19 +202,35 @@ def transform_two_body_sharded(u_bslab, C, C_tilde=None, rank=0, world=1, group=
 
 
 def transform_two_body_sharded_inplace(u_bslab, C, C_tilde=None, rank=0, world=1, group=None,
-                                       engine=HipEngine, staging_rows=1):
+                                       engine=HipEngine, staging_rows=1, out=None):
     """Memory-lean form of ``transform_two_body_sharded`` for tensors that only
-    just fit the node (BASELINE.json configs[4]: l = 512 complex128, 137 GB per
+    just fit the node (BASELINE.json configs[4]: l = 512 complex128, 128 GiB per
     GPU at G = 8).  Square transforms with ``l`` divisible by ``world`` only.
 
-    ``u_bslab = u[:, b_lo:b_hi]`` is DESTROYED: it is first overwritten, one
-    ``b`` at a time, by ``X[p, b, r, s] = Ct[p,a] u[a,b,c,d] C[c,r] C[d,s]`` (three
-    l^3-sized temporaries), then exchanged IN PLACE with the peers through a
-    small staging buffer -- the block of rows owned by peer g is swapped for the
-    block peer g holds for us, ``staging_rows`` rows per collective -- and
-    finally contracted over b into the freshly allocated result slab.  Peak
-    memory: input slab + output slab + O(l^3).  Same arithmetic as the
-    out-of-place layout, same single exchange step (chunked).
+    ``u_bslab = u[:, b_lo:b_hi]`` is left untouched (the per-step caller of
+    system.py:222-225 keeps ``u`` resident and transforms it again with the next
+    ``C(t)``); everything else happens INSIDE THE OUTPUT BUFFER, which is the
+    only slab-sized allocation: (pc + 1, l, l, l) elements for pc = l / world
+    result rows.
+
+    1. local phase, one ``b`` at a time (two l^3 temporaries): d, c, then the
+       contraction over ``a`` -- local in this layout -- writes
+       ``X[p, b, r, s] = Ct[p,a] u[a,b,c,d] C[c,r] C[d,s]`` into the buffer, the row
+       of global index ``p = g pc + p'`` going to slot ``(p', g)`` (the rows of
+       ``Ct`` are permuted once so that this is one plain GEMM per ``b``);
+    2. ONE exchange step, chunked: slot ``(p', g)`` -- what peer g needs from us
+       for its row p' -- is swapped for what peer g holds for our row p'
+       (``staging_rows`` rows per all-to-all through a staging buffer).  After
+       it slot ``(p', g)`` holds ``X[p_loc = p', b in slab(g)]``: row p' of the buffer
+       is the whole ``(b, (r, s))`` matrix of that result row, contiguous;
+    3. the contraction over b runs row by row in place: the product of row p'
+       is stored one row EARLIER than its operand (the buffer has one spare row
+       in front), so no copy and no second slab is ever needed.
+
+    Returns the view ``buffer[:pc]`` = ``out[p_lo:p_hi]``.  Peak memory: input
+    slab + output slab + one row + O(l^3) + staging.  Same arithmetic and the
+    same single exchange as the out-of-place layout.  ``out`` may supply the
+    buffer (contiguous, (pc + 1, l, l, l), result dtype) to reuse it across steps.
     """
     Ct = _bra(C, C_tilde)
     L, M = C.shape
@@ -220,13 +242,23 @@ def transform_two_body_sharded_inplace(u_bslab, C, C_tilde=None, rank=0, world=1
         raise ValueError(f"rank {rank}: expected a contiguous slab of shape {(L, bl, L, L)}")
     dt = kernels.result_dtype(u_bslab, C, Ct)
     if u_bslab.dtype != dt:
-        raise ValueError("the slab must already have the result dtype (it is overwritten in place)")
+        raise ValueError("the slab must already have the result dtype (no slab-sized cast is made)")
     C, Ct = C.to(dt).contiguous(), Ct.to(dt).contiguous()
     CT = C.transpose(0, 1).contiguous()
     dev = u_bslab.device
     L2, L3 = L * L, L * L * L
+    if out is None:
+        buf = torch.empty((pc + 1, L, L, L), dtype=dt, device=dev)
+    else:
+        if (tuple(out.shape) != (pc + 1, L, L, L) or out.dtype != dt or not out.is_contiguous()
+                or out.device != dev):
+            raise ValueError(f"`out` must be a contiguous {dt} buffer of shape {(pc + 1, L, L, L)}")
+        buf = out
+    # rows of Ct in slot order: slot p' * world + g  <-  global row g * pc + p'
+    order = torch.arange(L, device=Ct.device).reshape(world, pc).transpose(0, 1).reshape(-1)
+    Ct_slots = Ct[order].contiguous()
 
-    # ---- local phase, one b at a time:  u[:, j] -> X[:, j]
+    # ---- 1. local phase, one b at a time; X goes to rows 1 .. pc of the buffer
     t1 = torch.empty((L, L, L), dtype=dt, device=dev)
     t2 = torch.empty((L, L, L), dtype=dt, device=dev)
     for j in range(bl):
@@ -235,35 +267,34 @@ def transform_two_body_sharded_inplace(u_bslab, C, C_tilde=None, rank=0, world=1
                             a_off=j * L2)
         # c:  t2[a][r, s] = CT[r, c] t1[a][c, s]
         engine.gemm_strided(dt, CT, t1, t2, L, L, L, L, L, L, batch=L, sa=0, sb=L2, sc=L2)
-        # a:  X[p, j][(r, s)] = Ct[p, a] t2[a][(r, s)]       written over u[:, j] (row stride bl*L^2)
-        engine.gemm_strided(dt, Ct, t2, u_bslab, L, L2, L, L, L2, bl * L2, c_off=j * L2)
+        # a:  X[slot, j][(r, s)] = Ct_slots[slot, a] t2[a][(r, s)]      slots are bl*L^2 apart
+        engine.gemm_strided(dt, Ct_slots, t2, buf, L, L2, L, L, L2, bl * L2, c_off=L3 + j * L2)
     del t1, t2
-    x = u_bslab               # now X[p, b_loc, r, s]
 
-    # ---- exchange in place: rows p in slab(g) <-> what peer g holds for our rows
+    # ---- 2. exchange in place: slot (p', g) <-> what peer g holds for our row p'
+    x = buf[1:]                                   # (pc, L, L, L) = [p'][g][b][(r, s)]
     if world > 1:
         width = 2 if dt.is_complex else 1
-        row = bl * L2 * width                       # float64 words per p row of X
-        xf = _as_real_flat(x)                       # view
+        blk = bl * L2 * width                     # float64 words per slot
+        slots = _as_real_flat(x).reshape(pc, world, blk)          # view
         rows = max(1, min(int(staging_rows), pc))
-        send = torch.empty(world * rows * row, dtype=torch.float64, device=dev)
+        send = torch.empty((world, rows, blk), dtype=torch.float64, device=dev)
         recv = torch.empty_like(send)
         for r0 in range(0, pc, rows):
             nr = min(rows, pc - r0)
-            for g in range(world):
-                src = xf[(g * pc + r0) * row: (g * pc + r0 + nr) * row]
-                send[g * nr * row: (g + 1) * nr * row] = src
-            dist.all_to_all_single(recv[: world * nr * row], send[: world * nr * row], group=group)
-            for g in range(world):
-                xf[(g * pc + r0) * row: (g * pc + r0 + nr) * row] = recv[g * nr * row: (g + 1) * nr * row]
+            sv, rv = send[:, :nr], recv[:, :nr]
+            if nr != rows:
+                sv = torch.empty((world, nr, blk), dtype=torch.float64, device=dev)
+                rv = torch.empty_like(sv)
+            sv.copy_(slots[r0:r0 + nr].transpose(0, 1))
+            dist.all_to_all_single(rv.reshape(-1), sv.reshape(-1), group=group)
+            slots[r0:r0 + nr].copy_(rv.transpose(0, 1))
         del send, recv
 
-    # ---- b:  out[p][q, (r,s)] = sum_g Ct[q, b in slab(g)] X_g[p][b, (r,s)]   (zero-copy views of x)
-    out = torch.empty((pc, L, L2), dtype=dt, device=dev)
-    xv = x.reshape(world, pc, bl, L2)
-    for g in range(world):
-        engine.matmul(Ct[:, g * bl:(g + 1) * bl].contiguous(), xv[g], out=out, accumulate=g > 0)
-    return out.reshape(pc, L, L, L)
+    # ---- 3. b:  out[p'][q, (r,s)] = Ct[q, b] X[p'][b, (r,s)], stored one row earlier than X[p']
+    for p in range(pc):
+        engine.gemm_strided(dt, Ct, buf, buf, L, L2, L, L, L2, L2, b_off=(p + 1) * L3, c_off=p * L3)
+    return buf[:pc]
 
 
 # ---------------------------------------------------------------------------

@@ -96,6 +96,14 @@ def main():
                 slab4 = sharded.transform_two_body_sharded_inplace(
                     ub2, tC, tCt, rank, world, engine=OracleEngine, staging_rows=rows)
                 np.testing.assert_allclose(slab4.numpy(), ref[p_lo:p_hi], rtol=1e-12, atol=1e-12)
+                assert torch.equal(ub2, tu[:, b_lo:b_hi])           # the resident slab is untouched
+            # the buffer reused across steps, as a time loop would
+            keep = torch.empty((L // world + 1, L, L, L), dtype=slab4.dtype)
+            for _ in range(2):
+                slab5 = sharded.transform_two_body_sharded_inplace(
+                    ub2, tC, tCt, rank, world, engine=OracleEngine, staging_rows=3, out=keep)
+                np.testing.assert_allclose(slab5.numpy(), ref[p_lo:p_hi], rtol=1e-12, atol=1e-12)
+                assert slab5.data_ptr() == keep.data_ptr()
 
         # default bra (C^dagger) path
         slab3 = sharded.transform_two_body_sharded(ub, tC, None, rank, world, engine=OracleEngine)

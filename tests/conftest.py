@@ -33,3 +33,14 @@ def load_golden(name):
 @pytest.fixture
 def golden():
     return load_golden
+
+
+@pytest.fixture(autouse=True)
+def _automatic_kernel_choice():
+    """Tuning knobs are thread-local library state; whatever a test sets is
+    undone after it (also when it fails), so one test cannot change the kernel
+    dispatch of the next."""
+    yield
+    mod = sys.modules.get("quantum_systems_amd._lib")
+    if mod is not None and getattr(mod, "_lib", None) is not None:
+        mod._lib.qs_tuning_reset()

@@ -36,8 +36,25 @@ def test_transform_line_has_the_contract_fields():
     assert rf["bound"] == "mfma" and rf["unit"] == "TFLOP/s" and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-12
     cb = d["cpu_baseline"]
     assert cb["kind"] == "port" and cb["cores"] >= 1 and cb["value"] > 0 and "sample" in cb
-    assert d["parity"]["randomised_identity_rel_diff"] <= d["parity"]["bound"]
+    assert d["parity"]["randomised_identity_rel_diff"] <= d["parity"]["bound"] and d["parity"]["ok"] is True
     assert abs(d["value"] - 8 * 64**5 * 3 / (d["ms_per_step"] * 3e-3) / 1e12) < 1e-6 * d["value"]
+    # the kernel named in the line is the one the dispatcher took for this size (not a constant)
+    assert rf["kernel"].startswith("qs::gemm_fast_kernel<false, 2, 4, true, false>") and rf["launches_per_step"] == 4
+    assert d["ms_per_step_min"] <= d["ms_per_step_median"] and d["n_ranks_seen"] == 1
+    pts = {p["l"]: p for p in cb["points"]}
+    assert 55 in pts and pts[55]["einsum_optimize_s"] > 0 and pts[55]["tensordot_x4_s"] > 0
+
+
+def test_transform_line_names_the_small_basis_kernels():
+    d = run_bench("--orbitals", "55", "--no-cpu-baseline", "--no-probes")
+    assert "slab_pair" in d["roofline"]["dispatch"] and d["parity"]["ok"] is True
+
+
+def test_complex_time_evolution_pattern():
+    # BASELINE.json configs[4] call pattern: u resident, a new complex C(t) every step, C_tilde derived inside
+    d = run_bench("--orbitals", "64", "--dtype", "c128", "--no-cpu-baseline", "--no-probes")
+    assert d["dtype"] == "c128" and "a new C every step" in d["config"]["workload"] and d["parity"]["ok"] is True
+    assert d["roofline"]["kernel"].startswith("qs::gemm_fast_kernel<true")
 
 
 @pytest.mark.parametrize("workload", ["spin_expand", "antisymmetrize"])
@@ -49,21 +66,74 @@ def test_bandwidth_lines(workload):
     assert d["parity"]["value_exact_vs_definition"] is True
 
 
-@pytest.mark.parametrize("layout", ["replicated", "sharded"])
-def test_two_rank_launch_on_one_device(layout):
+REHEARSAL = dict(QS_BENCH_SINGLE_DEVICE="1", QS_BENCH_BACKEND="gloo", MASTER_ADDR="127.0.0.1")
+
+
+def test_two_rank_launch_by_the_external_launcher():
     # the N > 1 code path as the driver launches it (torch.distributed.run, one process per rank), rehearsed
     # on ONE GPU: both ranks on cuda:0 over gloo (QS_BENCH_SINGLE_DEVICE / QS_BENCH_BACKEND are rehearsal
     # hooks; the driver's real run uses one GPU per rank and RCCL)
-    env = dict(os.environ, QS_BENCH_SINGLE_DEVICE="1", QS_BENCH_BACKEND="gloo", MASTER_ADDR="127.0.0.1")
+    env = dict(os.environ, **REHEARSAL)
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
-           "--master-addr", "127.0.0.1", "--master-port", "29671" if layout == "replicated" else "29672",
+           "--master-addr", "127.0.0.1", "--master-port", "29671",
            os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--orbitals", "64",
-           "--layout", layout, "--no-cpu-baseline", "--no-probes"]
+           "--layout", "replicated", "--no-cpu-baseline", "--no-probes"]
     res = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=ROOT, env=env)
     assert res.returncode == 0, res.stderr[-3000:]
     lines = [ln for ln in res.stdout.splitlines() if ln.strip().startswith("{")]
     assert len(lines) == 1, res.stdout[-2000:]
     d = json.loads(lines[0])
-    assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["value"] > 0
-    if layout == "replicated":
-        assert d["parity"]["randomised_identity_rel_diff"] <= 1e-10
+    assert d["n_gpus"] == 2 and d["n_ranks_seen"] == 2 and d["scaling"] == "strong" and d["value"] > 0
+    assert d["parity"]["randomised_identity_rel_diff"] <= 1e-10
+
+
+@pytest.mark.parametrize("layout", ["auto", "replicated", "sharded", "inplace"])
+def test_two_rank_self_launch(layout):
+    # `python bench.py --gpus 2` with NO external launcher and no WORLD_SIZE: bench.py starts its two rank
+    # processes itself (before touching the GPU), waits, relays rank 0's single line -- the form the driver
+    # uses when it does not go through torch.distributed.run
+    env = dict(os.environ, **REHEARSAL)
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT"):
+        env.pop(k, None)
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
+           "--orbitals", "64", "--layout", layout, "--no-cpu-baseline", "--no-probes"]
+    res = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=ROOT, env=env)
+    assert res.returncode == 0, res.stderr[-3000:]
+    lines = [ln for ln in res.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, res.stdout[-2000:]                 # exactly one line on the parent's stdout
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["n_ranks_seen"] == 2 and d["steps"] == 3 and d["value"] > 0
+    assert d["parity"]["ok"] is True and d["parity"]["randomised_identity_rel_diff"] <= 1e-10
+    if layout in ("auto", "replicated"):
+        assert d["collective"]["in_value"] == "none" and d["with_all_gather"]["value"] > 0
+        assert d["with_all_gather"]["value"] <= d["value"] * 1.05
+    if layout == "inplace":
+        assert "in place" in d["config"]["layout"] and "per rank" in d["data"]
+
+
+def test_self_launch_bandwidth_workload_two_ranks():
+    env = dict(os.environ, **REHEARSAL)
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT"):
+        env.pop(k, None)
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+           "--orbitals", "32", "--workload", "spin_expand"]
+    res = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=ROOT, env=env)
+    assert res.returncode == 0, res.stderr[-3000:]
+    d = json.loads([ln for ln in res.stdout.splitlines() if ln.strip()][0])
+    assert d["n_gpus"] == 2 and d["parity"]["value_exact_vs_definition"] is True
+    assert d["roofline"]["kernel"] == "qs::spin_expand_kernel<double, f64x2>"
+
+
+def test_failed_parity_exits_nonzero(monkeypatch):
+    # the parity bound is enforced, not just printed: an impossible bound makes the run fail
+    import importlib.util
+
+    spec = importlib.util.spec_from_file_location("bench_under_test", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    monkeypatch.setattr(bench, "PARITY_BOUND", 0.0)
+    monkeypatch.setattr(sys, "argv", ["bench.py"])
+    args = bench.parse(["--orbitals", "32", "--steps", "1", "--warmup", "0", "--no-cpu-baseline", "--no-probes"])
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
+        monkeypatch.delenv(k, raising=False)
+    assert bench.run_rank(args) == 3

@@ -1,6 +1,6 @@
 """The sharded layouts driven by the HIP engine on one GPU (world = 1 and the
 per-rank pieces of larger worlds, where no collective is needed): strided
-batched products on sub-blocks, in-place overwrite of the input slab."""
+batched products on sub-blocks, exchange and last contraction inside the output buffer."""
 
 import numpy as np
 import pytest
@@ -29,8 +29,14 @@ def test_inplace_layout_world1_matches_oracle(cplx):
     out = sharded.transform_two_body_sharded_inplace(du, torch.from_numpy(C).cuda(), torch.from_numpy(Ct).cuda())
     got = out.cpu().numpy()
     assert np.abs(got - ref).max() <= 1e-10 * np.abs(ref).max()
-    # the input slab was consumed (overwritten by the intermediate X)
-    assert not np.array_equal(du.cpu().numpy(), u)
+    # the resident slab is untouched: everything happens inside the output buffer
+    assert np.array_equal(du.cpu().numpy(), u)
+    # the buffer reused across steps (time loop: u resident, new C every step)
+    keep = torch.empty((l + 1, l, l, l), dtype=du.dtype, device="cuda")
+    for _ in range(2):
+        again = sharded.transform_two_body_sharded_inplace(
+            du, torch.from_numpy(C).cuda(), torch.from_numpy(Ct).cuda(), out=keep)
+        assert again.data_ptr() == keep.data_ptr() and torch.equal(again, out)
     with pytest.raises(ValueError):
         sharded.transform_two_body_sharded_inplace(torch.from_numpy(u).cuda(), torch.from_numpy(C[:, :10].copy()).cuda())
 

@@ -51,6 +51,13 @@ def test_transforms_match_reference(golden, name):
         orc.transform_two_body_einsum(g["u"], g["C"], Ct), g["u_out"],
         rtol=1e-11, atol=1e-11,
     )
+    # the sampled form (what the l = 256 GPU test compares against) reproduces the reference's output too
+    M = g["u_out"].shape[0]
+    pairs = [(0, 0), (M - 1, 0), (M // 2, M - 1), (1 % M, 2 % M)]
+    np.testing.assert_allclose(
+        orc.transform_two_body_pq_samples(g["u"], g["C"], Ct, pairs),
+        np.stack([g["u_out"][p, q] for (p, q) in pairs]), rtol=1e-11, atol=1e-11,
+    )
 
 
 def test_spf_transforms_match_reference(golden):
