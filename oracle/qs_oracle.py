@@ -342,6 +342,48 @@ def change_to_general_orbital_basis(st, a=(1, 0), b=(0, 1), anti_symmetrize=True
 # --------------------------------------------------------------------------
 
 
+# --------------------------------------------------------------------------
+# f2  -- first consumers of (transformed) h, u: reference energy, Fock matrix
+# --------------------------------------------------------------------------
+
+
+def reference_energy(h, u, n_occ, nuclear_repulsion_energy=0.0, spin_orbitals=False):
+    """Energy of the reference determinant with ``n_occ`` occupied ORBITALS of the basis.
+
+    closed shell over spatial orbitals (quantum_systems/spatial_orbital_system.py:140-150):
+        2 h_ii + 2 u_ijij - u_ijji + E_nuc
+    spin orbitals with anti-symmetrised u (quantum_systems/general_orbital_system.py:108-121):
+        h_ii + 1/2 u_ijij + E_nuc
+    written with the same nested traces as the reference."""
+    o = slice(0, n_occ)
+    if spin_orbitals:
+        return (
+            np.trace(h[o, o])
+            + 0.5 * np.trace(np.trace(u[o, o, o, o], axis1=1, axis2=3))
+            + nuclear_repulsion_energy
+        )
+    return (
+        2 * np.trace(h[o, o])
+        + 2 * np.trace(np.trace(u[o, o, o, o], axis1=1, axis2=3))
+        - np.trace(np.trace(u[o, o, o, o], axis1=1, axis2=2))
+        + nuclear_repulsion_energy
+    )
+
+
+def fock_matrix(h, u, n_occ, spin_orbitals=False):
+    """closed shell (spatial_orbital_system.py:176-190): f_pq = h_pq + 2 u_piqi - u_piiq;
+    spin orbitals (general_orbital_system.py:147-159): f_pq = h_pq + u_piqi."""
+    o = slice(0, n_occ)
+    f = np.zeros_like(h)
+    f += h
+    if spin_orbitals:
+        f += np.einsum("piqi -> pq", u[:, o, :, o])
+        return f
+    f += 2 * np.einsum("piqi -> pq", u[:, o, :, o])
+    f -= np.einsum("piiq -> pq", u[:, o, o, :])
+    return f
+
+
 def transform_flops(L, M, complex_=False):
     """2(L^4 M + L^3 M^2 + L^2 M^3 + L M^4) real flops, x4 for complex128."""
     k = 4 if complex_ else 1

@@ -350,17 +350,11 @@ def construct_fock_matrix_sharded(h, u_slab, n_occ, rank=0, world=1, spin_orbita
     return f
 
 
-def reference_energy_sharded(h, u_slab, n_occ, rank=0, world=1, spin_orbitals=False,
-                             nuclear_repulsion_energy=0.0, group=None):
-    """Reference-determinant energy from a p-sharded ``u``.
-
-    spatial (spatial_orbital_system.py:106-150): 2 h_ii + 2 u_ijij - u_ijji + E_nuc
-    spin orbitals (general_orbital_system.py:75-121): h_ii + 1/2 u_ijij + E_nuc
-    The leading index i of ``u`` is the sharded one: each rank sums its occupied
-    rows, one all-reduce of a single number closes the sum.
-    """
-    l = h.shape[0]
-    lo, hi = SlabPartition(l, world).bounds(rank)
+def reference_energy_partial(h, u_slab, n_occ, p_lo, spin_orbitals=False):
+    """This slab's share of the reference-determinant energy (no nuclear term): the sum over the occupied
+    rows i in [p_lo, p_lo + rows) of  2 h_ii + 2 u_ijij - u_ijji  (spatial orbitals) or  h_ii + 1/2 u_ijij
+    (spin orbitals, anti-symmetrised u); the shares of all slabs add up to the energy."""
+    lo, hi = p_lo, p_lo + u_slab.shape[0]
     i_lo, i_hi = min(lo, n_occ), min(hi, n_occ)          # occupied rows of this slab
     o = slice(0, n_occ)
     part = torch.zeros((), dtype=u_slab.dtype, device=u_slab.device)
@@ -372,6 +366,23 @@ def reference_energy_sharded(h, u_slab, n_occ, rank=0, world=1, spin_orbitals=Fa
             part = hd + 0.5 * coul
         else:
             part = 2 * hd + 2 * coul - torch.einsum("ijji->", u_slab[i_lo - lo:i_hi - lo, o, o, :][:, :, :, i_lo:i_hi])
+    return part
+
+
+def reference_energy_sharded(h, u_slab, n_occ, rank=0, world=1, spin_orbitals=False,
+                             nuclear_repulsion_energy=0.0, group=None):
+    """Reference-determinant energy from a p-sharded ``u``.
+
+    spatial (spatial_orbital_system.py:106-150): 2 h_ii + 2 u_ijij - u_ijji + E_nuc
+    spin orbitals (general_orbital_system.py:75-121): h_ii + 1/2 u_ijij + E_nuc
+    The leading index i of ``u`` is the sharded one: each rank sums its occupied
+    rows, one all-reduce of a single number closes the sum.
+    """
+    l = h.shape[0]
+    lo, hi = SlabPartition(l, world).bounds(rank)
+    if u_slab.shape[0] != hi - lo:
+        raise ValueError(f"rank {rank}: slab has {u_slab.shape[0]} rows, expected {hi - lo}")
+    part = reference_energy_partial(h, u_slab, n_occ, lo, spin_orbitals)
     if world > 1:
         buf = torch.view_as_real(part.to(torch.complex128).reshape(1)).reshape(-1).contiguous()
         dist.all_reduce(buf, group=group)

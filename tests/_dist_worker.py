@@ -131,6 +131,24 @@ def main():
             e = sharded.reference_energy_sharded(th, tslab, n_occ, rank, world, spin_orbitals=spin,
                                                  nuclear_repulsion_energy=0.25)
             np.testing.assert_allclose(complex(e), e_ref, rtol=1e-12, atol=1e-12)
+    # ... and pinned to the reference itself: values computed by its SpatialOrbitalSystem /
+    # GeneralOrbitalSystem on a seeded RandomBasisSet (tests/golden/fock_energy_random_basis.npz)
+    with np.load(os.path.join(ROOT, "tests", "golden", "fock_energy_random_basis.npz")) as z:
+        g = {k: z[k] for k in z.files}
+    n_occ = int(g["n"]) // 2
+    st = dict(h=g["h"], u=g["u"])
+    gos = orc.new_state(int(g["l"]), 2)
+    gos.update(h=g["h"].copy(), u=g["u"].copy(), s=g["s"].copy())
+    gos = orc.change_to_general_orbital_basis(gos)
+    for (h, u, n, spin, f_ref, e_ref) in ((st["h"], st["u"], n_occ, False, g["spas_fock"], g["spas_energy"]),
+                                          (gos["h"], gos["u"], 2 * n_occ, True, g["gos_fock"], g["gos_energy"])):
+        lo, hi = sharded.SlabPartition(h.shape[0], world).bounds(rank)
+        th, tslab = torch.from_numpy(h), torch.from_numpy(np.ascontiguousarray(u[lo:hi]))
+        f = sharded.construct_fock_matrix_sharded(th, tslab, n, rank, world, spin_orbitals=spin)
+        np.testing.assert_allclose(f.numpy(), f_ref, rtol=1e-12, atol=1e-12)
+        e = sharded.reference_energy_sharded(th, tslab, n, rank, world, spin_orbitals=spin,
+                                             nuclear_repulsion_energy=float(g["e_nuc"]))
+        np.testing.assert_allclose(complex(e), e_ref, rtol=1e-12, atol=1e-12)
     dist.barrier()
     dist.destroy_process_group()
     print(f"rank {rank}/{world} ok")

@@ -429,7 +429,62 @@ def case_tdho_one_body():
     save("tdho_one_body", **out)
 
 
+def case_fock_energy():
+    """Fock matrix and reference energy of the reference's own system classes
+    (spatial_orbital_system.py:106-190, general_orbital_system.py:75-159) on seeded
+    RandomBasisSets: before and after a change of basis, closed-shell and spin-orbital."""
+    out = {}
+    np.random.seed(4242)
+    l, n = 8, 4
+    bs = qs.RandomBasisSet(l, 2)
+    spas = qs.SpatialOrbitalSystem(n, bs)
+    out["n"], out["l"] = np.int64(n), np.int64(l)
+    out["h"], out["u"], out["s"] = spas.h.copy(), spas.u.copy(), spas.s.copy()
+    out["e_nuc"] = np.float64(spas.nuclear_repulsion_energy)
+    out["spas_energy"] = np.complex128(spas.compute_reference_energy())
+    out["spas_fock"] = spas.construct_fock_matrix(spas.h, spas.u)
+    # custom (h, u) arguments: occupied block only, as the docstring allows
+    o = spas.o
+    out["spas_energy_occ_block"] = np.complex128(
+        spas.compute_reference_energy(h=spas.h[o, o], u=spas.u[o, o, o, o]))
+    gos = spas.construct_general_orbital_system()
+    out["gos_energy"] = np.complex128(gos.compute_reference_energy())
+    out["gos_fock"] = gos.construct_fock_matrix(gos.h, gos.u)
+    out["gos_h"] = gos.h.copy()
+    rng = np.random.default_rng(77)
+    C, _ = np.linalg.qr(crand(rng, l, l))
+    out["C"] = C
+    spas.change_basis(C)
+    out["spas_cb_energy"] = np.complex128(spas.compute_reference_energy())
+    out["spas_cb_fock"] = spas.construct_fock_matrix(spas.h, spas.u)
+    C2, _ = np.linalg.qr(crand(rng, 2 * l, 2 * l))
+    out["C_gos"] = C2
+    gos.change_basis(C2)
+    out["gos_cb_energy"] = np.complex128(gos.compute_reference_energy())
+    out["gos_cb_fock"] = gos.construct_fock_matrix(gos.h, gos.u)
+    # f buffer argument: filled in place and returned
+    f = np.ones_like(gos.h)
+    ret = gos.construct_fock_matrix(gos.h, gos.u, f=f)
+    assert ret is f
+    # a second, larger closed-shell case with a rectangular (shrinking) change of basis
+    np.random.seed(99)
+    l2, n2 = 10, 6
+    spas2 = qs.SpatialOrbitalSystem(n2, qs.RandomBasisSet(l2, 1))
+    out["b_n"], out["b_l"] = np.int64(n2), np.int64(l2)
+    out["b_h"], out["b_u"] = spas2.h.copy(), spas2.u.copy()
+    out["b_e_nuc"] = np.float64(spas2.nuclear_repulsion_energy)
+    Cr = crand(rng, l2, 8)
+    out["b_C"] = Cr
+    spas2.change_basis(Cr)
+    out["b_cb_energy"] = np.complex128(spas2.compute_reference_energy())
+    out["b_cb_fock"] = spas2.construct_fock_matrix(spas2.h, spas2.u)
+    save("fock_energy_random_basis", **out)
+
+
 if __name__ == "__main__":
+    if len(sys.argv) > 1 and sys.argv[1] == "fock":
+        case_fock_energy()
+        sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "tdho1":
         case_tdho_one_body()
         sys.exit(0)
@@ -448,3 +503,4 @@ if __name__ == "__main__":
     case_tdho_coulomb()
     case_odqd()
     case_tdho_one_body()
+    case_fock_energy()

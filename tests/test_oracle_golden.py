@@ -232,3 +232,52 @@ def test_rectangular_change_of_basis_like_reference():
     assert st["l"] == new_l and st["u"].shape == (new_l,) * 4
     np.testing.assert_allclose(h_ref, st["h"], atol=1e-12, rtol=1e-12)
     np.testing.assert_allclose(u_ref, st["u"], atol=1e-12, rtol=1e-12)
+
+
+# ------------------------------------------------------------------ f2: Fock matrix / reference energy
+
+
+def _fock_state(g, prefix=""):
+    l = int(g[prefix + "l"])
+    st = orc.new_state(l, 2)
+    st["h"], st["u"] = g[prefix + "h"].copy(), g[prefix + "u"].copy()
+    st["s"] = g["s"].copy() if not prefix else np.eye(l, dtype=np.complex128)
+    st["nuclear_repulsion_energy"] = float(g[prefix + "e_nuc"])
+    return st
+
+
+def test_fock_and_energy_match_reference_classes(golden):
+    # SpatialOrbitalSystem / GeneralOrbitalSystem of the reference on a seeded RandomBasisSet
+    # (spatial_orbital_system.py:106-190, general_orbital_system.py:75-159), before and after change_basis
+    g = golden("fock_energy_random_basis")
+    n = int(g["n"]) // 2          # n particles -> n // 2 doubly occupied spatial orbitals (spatial_orbital_system.py:50)
+    st = _fock_state(g)
+    e = orc.reference_energy(st["h"], st["u"], n, st["nuclear_repulsion_energy"])
+    np.testing.assert_allclose(e, g["spas_energy"], **TIGHT)
+    np.testing.assert_allclose(orc.fock_matrix(st["h"], st["u"], n), g["spas_fock"], **TIGHT)
+    o = slice(0, n)
+    np.testing.assert_allclose(
+        orc.reference_energy(st["h"][o, o], st["u"][o, o, o, o], n, st["nuclear_repulsion_energy"]),
+        g["spas_energy_occ_block"], **TIGHT)
+    gos = orc.change_to_general_orbital_basis(_fock_state(g))
+    np.testing.assert_allclose(gos["h"], g["gos_h"], **TIGHT)
+    np.testing.assert_allclose(
+        orc.reference_energy(gos["h"], gos["u"], 2 * n, gos["nuclear_repulsion_energy"], spin_orbitals=True),
+        g["gos_energy"], **TIGHT)
+    np.testing.assert_allclose(orc.fock_matrix(gos["h"], gos["u"], 2 * n, spin_orbitals=True), g["gos_fock"], **TIGHT)
+    orc.change_basis(st, g["C"])
+    np.testing.assert_allclose(
+        orc.reference_energy(st["h"], st["u"], n, st["nuclear_repulsion_energy"]), g["spas_cb_energy"], **TIGHT)
+    np.testing.assert_allclose(orc.fock_matrix(st["h"], st["u"], n), g["spas_cb_fock"], **TIGHT)
+    orc.change_basis(gos, g["C_gos"])
+    np.testing.assert_allclose(
+        orc.reference_energy(gos["h"], gos["u"], 2 * n, gos["nuclear_repulsion_energy"], spin_orbitals=True),
+        g["gos_cb_energy"], **TIGHT)
+    np.testing.assert_allclose(orc.fock_matrix(gos["h"], gos["u"], 2 * n, spin_orbitals=True), g["gos_cb_fock"], **TIGHT)
+    # second case: rectangular (shrinking) change of basis
+    sb = _fock_state(g, "b_")
+    orc.change_basis(sb, g["b_C"])
+    nb = int(g["b_n"]) // 2
+    np.testing.assert_allclose(
+        orc.reference_energy(sb["h"], sb["u"], nb, sb["nuclear_repulsion_energy"]), g["b_cb_energy"], **TIGHT)
+    np.testing.assert_allclose(orc.fock_matrix(sb["h"], sb["u"], nb), g["b_cb_fock"], **TIGHT)
