@@ -191,12 +191,18 @@ def make_u_slab(torch, l, dtype, device, axis, lo, hi, seed=1234, centre=False):
 
 
 def contract4(t, va, vb, vc, vd):
-    """sum_abcd t[a,b,c,d] va[a] vb[b] vc[c] vd[d] as four matrix-vector products (no tensor-sized temporary)."""
+    """sum_abcd t[a,b,c,d] va[a] vb[b] vc[c] vd[d] as matrix-vector products over blocks of leading rows
+    (no tensor-sized temporary; blocks of <= 2^18 rows: rocBLAS gemv rejects the 1.7e7-row call)."""
+    import torch
+
     A, B, C, D = t.shape
-    x = t.reshape(-1, D) @ vd
-    x = x.reshape(-1, C) @ vc
-    x = x.reshape(A, B) @ vb
-    return x @ va
+    step = max(1, (1 << 18) // (B * C))
+    parts = []
+    for a0 in range(0, A, step):
+        x = t[a0:a0 + step].reshape(-1, D) @ vd
+        x = x.reshape(-1, C) @ vc
+        parts.append(x.reshape(-1, B) @ vb)
+    return torch.cat(parts) @ va
 
 
 def identity_parts(torch, u_part, out_rows, C, Ct, p_lo, b_lo=None, seed=7):

@@ -150,6 +150,19 @@ int qs_spin_expand_two_body(int in_dtype, int out_dtype, const void* u,
                             int antisymmetrize, void* stream);
 
 /*
+ * The same expansion for a BLOCK of the tensor, the form the sharded layouts
+ * use (no rank holds the whole tensor):
+ *   u   : (np, nq, l, l)  = u[p0:p0+np, q0:q0+nq, :, :], contiguous
+ *   out : (2 np, 2 nq, 2l, 2l) = out[2 p0 : 2(p0+np), 2 q0 : 2(q0+nq), :, :]
+ * np = rows of a leading-index slab with nq = l, or np = l with nq = the rows
+ * of a second-index slab.  Slab-local: output element (2p+s1, 2q+s2, ., .)
+ * needs input matrix (p, q) only.
+ */
+int qs_spin_expand_two_body_block(int in_dtype, int out_dtype, const void* u,
+                                  void* out, int64_t l, int64_t np, int64_t nq,
+                                  int antisymmetrize, void* stream);
+
+/*
  * kron(h, I2) for a stack of matrices: out[i, 2p+s, 2q+t] = d(s,t) h[i,p,q]
  *   h : (nmat, l, l) in_dtype     out : (nmat, 2l, 2l) out_dtype
  * Replaces BasisSet.add_spin_one_body, basis_set.py:768-770.

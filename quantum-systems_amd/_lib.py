@@ -36,6 +36,8 @@ SIGNATURES = {
     "qs_antisymmetrize": (c_int, [c_int, c_ptr, c_ptr, c_i64, c_i64, c_ptr]),
     "qs_spin_expand_two_body": (
         c_int, [c_int, c_int, c_ptr, c_ptr, c_i64, c_i64, c_i64, c_int, c_ptr]),
+    "qs_spin_expand_two_body_block": (
+        c_int, [c_int, c_int, c_ptr, c_ptr, c_i64, c_i64, c_i64, c_int, c_ptr]),
     "qs_add_spin_one_body": (c_int, [c_int, c_int, c_ptr, c_ptr, c_i64, c_i64, c_ptr]),
     "qs_spin_squared_two_body": (c_int, [c_ptr, c_ptr, c_i64, c_i64, c_i64, c_int, c_ptr]),
     "qs_tdho_coulomb_elements": (c_int, [c_ptr, c_i64, c_i64, c_i64, c_ptr]),

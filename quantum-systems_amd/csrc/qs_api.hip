@@ -306,7 +306,20 @@ int qs_spin_expand_two_body(int in_dtype, int out_dtype, const void* u, void* ou
     if (!u || !out) return QS_ERR_NULL_POINTER;
     if (!aligned(u, elem_size(in_dtype)) || !aligned(out, elem_size(out_dtype))) return QS_ERR_MISALIGNED;
     if (out == u) return QS_ERR_ALIAS;
-    return spin_expand(in_dtype, out_dtype, u, out, l, p_lo, p_hi, antisymmetrize_flag ? 1 : 0,
+    return spin_expand(in_dtype, out_dtype, u, out, l, l, p_lo, p_hi, antisymmetrize_flag ? 1 : 0,
+                       (hipStream_t)stream);
+}
+
+int qs_spin_expand_two_body_block(int in_dtype, int out_dtype, const void* u, void* out, int64_t l,
+                                  int64_t np, int64_t nq, int antisymmetrize_flag, void* stream) {
+    dispatch_reset();
+    if (!dtype_ok(in_dtype) || !dtype_ok(out_dtype)) return QS_ERR_BAD_DTYPE;
+    if (in_dtype == QS_C128 && out_dtype == QS_F64) return QS_ERR_BAD_DTYPE;
+    if (l <= 0 || l > 32768 || np <= 0 || np > l || nq <= 0 || nq > l) return QS_ERR_BAD_EXTENT;
+    if (!u || !out) return QS_ERR_NULL_POINTER;
+    if (!aligned(u, elem_size(in_dtype)) || !aligned(out, elem_size(out_dtype))) return QS_ERR_MISALIGNED;
+    if (out == u) return QS_ERR_ALIAS;
+    return spin_expand(in_dtype, out_dtype, u, out, l, nq, 0, np, antisymmetrize_flag ? 1 : 0,
                        (hipStream_t)stream);
 }
 

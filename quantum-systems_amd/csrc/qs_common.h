@@ -102,7 +102,7 @@ int transpose_small(int dtype, const void* in, void* out, int64_t rows,
 
 // Bandwidth kernels (qs_permute.hip).
 int antisymmetrize(int dtype, const void* u, void* out, int64_t npq, int64_t l, hipStream_t stream);
-int spin_expand(int in_dtype, int out_dtype, const void* u, void* out, int64_t l, int64_t p_lo,
+int spin_expand(int in_dtype, int out_dtype, const void* u, void* out, int64_t l, int64_t nq, int64_t p_lo,
                 int64_t p_hi, int as, hipStream_t stream);
 int kron_eye2(int in_dtype, int out_dtype, const void* h, void* out, int64_t nmat, int64_t l,
               hipStream_t stream);

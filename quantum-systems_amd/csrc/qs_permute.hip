@@ -123,15 +123,17 @@ __device__ __forceinline__ void spin_write_block(TO* __restrict__ o, int n2, con
 
 template <typename TI, typename TO>
 __global__ __launch_bounds__(256) void spin_expand_kernel(const TI* __restrict__ u, TO* __restrict__ out,
-                                                          int l, int nt, int npairs, int p_lo, int as) {
+                                                          int l, int nq, int nt, int npairs, int p_lo, int as) {
+    // u is a block (rows, nq, l, l) of the tensor: nq = l for a leading-index slab, fewer for a slab of
+    // the second index; the output block is (2 rows, 2 nq, 2l, 2l)
     __shared__ TI t1[PT][PS];
     __shared__ TI t2[PT][PS];
-    const int64_t pq = blockIdx.x / npairs;                // local (p - p_lo) * l + q
+    const int64_t pq = blockIdx.x / npairs;                // local (p - p_lo) * nq + q
     const int pair = blockIdx.x % npairs;
     int ti, tj;
     tile_pair(pair, nt, ti, tj);
-    const int64_t pl = pq / l, q = pq % l;
-    const TI* m = u + ((pl + p_lo) * (int64_t)l + q) * (int64_t)l * l;
+    const int64_t pl = pq / nq, q = pq % nq;
+    const TI* m = u + ((pl + p_lo) * (int64_t)nq + q) * (int64_t)l * l;
     load_tile(t1, m, l, ti * PT, tj * PT);
     if (ti != tj) load_tile(t2, m, l, tj * PT, ti * PT);
     __syncthreads();
@@ -140,7 +142,7 @@ __global__ __launch_bounds__(256) void spin_expand_kernel(const TI* __restrict__
 #pragma unroll
     for (int s12 = 0; s12 < 4; ++s12) {
         const int s1 = s12 >> 1, s2 = s12 & 1;
-        TO* o = out + ((2 * pl + s1) * (int64_t)n2 + (2 * q + s2)) * mat;
+        TO* o = out + ((2 * pl + s1) * (int64_t)(2 * nq) + (2 * q + s2)) * mat;
         if (ti == tj) {
             spin_write_block<TI, TO>(o, n2, t1, t1, l, ti * PT, tj * PT, s1, s2, as != 0);
         } else {
@@ -253,22 +255,22 @@ int antisymmetrize(int dtype, const void* u, void* out, int64_t npq, int64_t l, 
     return launch_status("antisymmetrize launch");
 }
 
-int spin_expand(int in_dtype, int out_dtype, const void* u, void* out, int64_t l, int64_t p_lo,
+int spin_expand(int in_dtype, int out_dtype, const void* u, void* out, int64_t l, int64_t nq, int64_t p_lo,
                 int64_t p_hi, int as, hipStream_t stream) {
     const int nt = (int)cdiv(l, PT);
     const int64_t npairs = (int64_t)nt * (nt + 1) / 2;
-    const int64_t nwg = (p_hi - p_lo) * l * npairs;
+    const int64_t nwg = (p_hi - p_lo) * nq * npairs;
     if (nwg >= (int64_t(1) << 31)) return QS_ERR_BAD_EXTENT;
     const dim3 grid((unsigned)nwg), block(256);
     if (in_dtype == QS_F64 && out_dtype == QS_F64)
         hipLaunchKernelGGL((spin_expand_kernel<double, double>), grid, block, 0, stream,
-                           (const double*)u, (double*)out, (int)l, nt, (int)npairs, (int)p_lo, as);
+                           (const double*)u, (double*)out, (int)l, (int)nq, nt, (int)npairs, (int)p_lo, as);
     else if (in_dtype == QS_F64 && out_dtype == QS_C128)
         hipLaunchKernelGGL((spin_expand_kernel<double, f64x2>), grid, block, 0, stream,
-                           (const double*)u, (f64x2*)out, (int)l, nt, (int)npairs, (int)p_lo, as);
+                           (const double*)u, (f64x2*)out, (int)l, (int)nq, nt, (int)npairs, (int)p_lo, as);
     else if (in_dtype == QS_C128 && out_dtype == QS_C128)
         hipLaunchKernelGGL((spin_expand_kernel<f64x2, f64x2>), grid, block, 0, stream,
-                           (const f64x2*)u, (f64x2*)out, (int)l, nt, (int)npairs, (int)p_lo, as);
+                           (const f64x2*)u, (f64x2*)out, (int)l, (int)nq, nt, (int)npairs, (int)p_lo, as);
     else
         return QS_ERR_BAD_DTYPE;
     note_dispatch("qs::spin_expand_kernel<%s, %s>", in_dtype == QS_F64 ? "double" : "f64x2",

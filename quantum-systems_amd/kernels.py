@@ -408,6 +408,35 @@ def spin_expand_two_body(u, antisymmetrize=False, out_dtype=None, p_lo=0, p_hi=N
     return out
 
 
+def spin_expand_two_body_block(u_block, antisymmetrize=False, out_dtype=None, out=None):
+    """Spin doubling of a block ``u[p0:p0+np, q0:q0+nq, :, :]`` of shape (np, nq, l, l) ->
+    (2 np, 2 nq, 2l, 2l): what a rank of a sharded tensor holds, whichever of the two leading
+    indices is the sharded one (basis_set.py:772-778, :634 on the rank's share)."""
+    lib = _lib.load()
+    dt = result_dtype(u_block)
+    u_block = _dev(u_block, dt)
+    if u_block.dim() != 4 or u_block.shape[2] != u_block.shape[3]:
+        raise ValueError("u_block must be (np, nq, l, l)")
+    np_, nq, l = u_block.shape[0], u_block.shape[1], u_block.shape[3]
+    if np_ > l or nq > l or np_ < 1 or nq < 1:
+        raise ValueError("block extents must be within 1..l")
+    odt = dt if out_dtype is None else out_dtype
+    shape = (2 * np_, 2 * nq, 2 * l, 2 * l)
+    if out is None:
+        out = torch.empty(shape, dtype=odt, device=u_block.device)
+    else:
+        _check_out(out, shape, odt, "spin_expand_two_body_block")
+    with _on_device_of(u_block, out):
+        _ran(
+            lib.qs_spin_expand_two_body_block(
+                dtype_code(dt), dtype_code(odt), u_block.data_ptr(), out.data_ptr(), l, np_, nq,
+                1 if antisymmetrize else 0, _stream(),
+            ),
+            "qs_spin_expand_two_body_block",
+        )
+    return out
+
+
 def add_spin_one_body(h, out_dtype=None):
     """``kron(h, I2)`` for (l,l) or a stack (n,l,l) (basis_set.py:768-770)."""
     lib = _lib.load()

@@ -40,10 +40,13 @@ def test_config2_l256_sampled_rows_and_identity_vs_oracle():
     # randomised identity over the whole result: sum out x y z w == sum u (Ct^T x)(Ct^T y)(C z)(C w)
     x, y, z, w = [torch.randn(L, dtype=torch.float64, device="cuda:0", generator=g) for _ in range(4)]
 
-    def contract(t, a, b, c, d):
-        v = t.reshape(-1, L) @ d
-        v = v.reshape(-1, L) @ c
-        return (v.reshape(L, L) @ b) @ a
+    def contract(t, a, b, c, d):          # blocks of 4 leading rows: rocBLAS gemv rejects a 1.7e7-row call
+        parts = []
+        for a0 in range(0, L, 4):
+            v = t[a0:a0 + 4].reshape(-1, L) @ d
+            v = v.reshape(-1, L) @ c
+            parts.append(v.reshape(-1, L) @ b)
+        return torch.cat(parts) @ a
 
     Ct = C.t().contiguous()
     lhs = contract(out, x, y, z, w)
