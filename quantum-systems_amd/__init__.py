@@ -13,6 +13,7 @@ import it as ``quantum_systems_amd`` (the sibling shim package aliases it).
 
 from . import _lib, kernels, sharded  # noqa: F401
 from .array_module import DeviceArray, DeviceModule, hip
+from .sharded_module import ShardedDeviceModule, ShardedTensor4
 from .basis_set import BasisSet
 from .custom_system import construct_custom_system, setup_basis_set
 from .general_orbital_system import GeneralOrbitalSystem
@@ -27,5 +28,5 @@ __all__ = [
     "BasisSet", "RandomBasisSet", "QuantumSystem", "SpatialOrbitalSystem",
     "GeneralOrbitalSystem", "setup_basis_set", "construct_custom_system",
     "TwoDimensionalHarmonicOscillator", "TwoDimensionalDoubleWell", "TwoDimHarmonicOscB", "ODQD", "ODSincDVR",
-    "hip", "DeviceModule", "DeviceArray", "kernels", "sharded",
+    "hip", "DeviceModule", "DeviceArray", "ShardedDeviceModule", "ShardedTensor4", "kernels", "sharded",
 ]

@@ -24,8 +24,9 @@ import warnings
 import numpy
 import torch
 
-from . import kernels
+from . import kernels, sharded_basis
 from .array_module import convert, is_device_module, to_host, wrap
+from .sharded_module import is_sharded, is_sharded_module
 from .system_helper import compute_particle_density
 
 _ARRAY_FIELDS = (
@@ -177,6 +178,8 @@ class BasisSet:
         """Two-body S^2.  At (2l)^4 complex elements it is as large as ``u``;
         the spin doubling records how to build it and the tensor is produced on
         first access (SURVEY 7 "memory capacity")."""
+        if self._spin_2_tb is None and self._spin_2_tb_recipe is not None and is_sharded_module(self.np):
+            self._spin_2_tb = sharded_basis.spin_2_tb_rows(self)      # this rank's rows only
         if self._spin_2_tb is None and self._spin_2_tb_recipe is not None:
             stack, anti = self._spin_2_tb_recipe
             self._spin_2_tb_recipe = None
@@ -203,7 +206,15 @@ class BasisSet:
         self.np = np
         self.bra_spf  # materialise the lazy dual before converting, as :287 does
         for slot in _ARRAY_FIELDS:
-            setattr(self, slot, convert(getattr(self, slot), np))
+            arr = getattr(self, slot)
+            if slot in ("_u", "_spin_2_tb") and arr is not None and len(arr.shape) == 4:
+                if is_sharded_module(np):
+                    # rank-4 tensors become one slab per rank: only this rank's rows are kept / uploaded
+                    setattr(self, slot, np.shard(arr, axis=arr.axis if is_sharded(arr) else 0))
+                    continue
+                if is_sharded(arr):
+                    arr = arr.gather()      # leaving the sharded module: the whole tensor on every rank
+            setattr(self, slot, convert(arr, np))
         if self._spin_2_tb_recipe is not None:
             stack, anti = self._spin_2_tb_recipe
             self._spin_2_tb_recipe = (convert(stack, np), anti)
@@ -255,7 +266,13 @@ class BasisSet:
     def transform_two_body_elements(u, C, np, C_tilde=None):
         """out[pqrs] = Ct[pa] Ct[qb] u[abcd] C[cr] C[ds] (:336-350), four
         single-index contractions in the reference's order d, c, b, a.  Returns
-        a new array; ``u`` is left untouched."""
+        a new array; ``u`` is left untouched.  A sharded ``u`` (``np`` = the sharded module) returns a
+        sharded result: one all-to-all, see sharded_basis.transform_two_body."""
+        if is_sharded(u):
+            d_C = np.asarray(C).as_subclass(torch.Tensor).contiguous()
+            d_Ct = (kernels.default_bra(d_C) if C_tilde is None
+                    else np.asarray(C_tilde).as_subclass(torch.Tensor).contiguous())
+            return sharded_basis.transform_two_body(u, d_C, d_Ct, np)
         Ct = None if C_tilde is None else _stage(C_tilde)
         return _deliver(kernels.transform_two_body(_stage(u), _stage(C), Ct), np)
 
@@ -269,6 +286,8 @@ class BasisSet:
         """In-place change of basis with ket coefficients ``C`` (l_old, l_new)
         and bra coefficients ``C_tilde`` (l_new, l_old), default ``C^dagger``
         (:413-464).  Rectangular ``C`` changes ``l``."""
+        if is_sharded_module(self.np):
+            return sharded_basis.change_basis(self, C, C_tilde)
         np = self.np
         self.l = C.shape[1]                                     # :448
         d_C = _stage(C)
@@ -316,14 +335,32 @@ class BasisSet:
     @staticmethod
     def anti_symmetrize_u(_u):
         """``u[pqrs] - u[pqsr]`` as a new array (:776-778)."""
+        if is_sharded(_u):
+            return _u._like(kernels.antisymmetrize(_u.local))
         out = kernels.antisymmetrize(_stage(_u))
         if isinstance(_u, torch.Tensor):
             return wrap(out)
         return to_host(out)
 
+    def _statics_overridden(self):
+        """True when a subclass replaces the spin / anti-symmetry statics (ODSincDVR does, for its 2-d
+        ``u``): the drivers then go through ``self.add_spin_two_body`` / ``self.anti_symmetrize_u`` exactly
+        as :523 and :576 do, instead of the fused kernels written for the rank-4 tensor."""
+        cls = type(self)
+        return (cls.add_spin_two_body is not BasisSet.add_spin_two_body
+                or cls.anti_symmetrize_u is not BasisSet.anti_symmetrize_u)
+
     def anti_symmetrize_two_body_elements(self):
         """Anti-symmetrise ``u`` and ``spin_2_tb`` once (:511-528)."""
         if self._anti_symmetrized_u:
+            return
+        if is_sharded(self._u):
+            return sharded_basis.anti_symmetrize_two_body_elements(self)
+        if self._statics_overridden() or len(self.u.shape) != 4:
+            self.u = self.anti_symmetrize_u(self.u)                       # :523
+            if self.spin_2_tb is not None:
+                self.spin_2_tb = self.anti_symmetrize_u(self.spin_2_tb)   # :525-526
+            self._anti_symmetrized_u = True
             return
         d = _stage(self.u)
         on_device = d is self.u or isinstance(self.u, torch.Tensor)
@@ -407,6 +444,8 @@ class BasisSet:
         operators are set up in the spinor basis {a, b} and all arrays end up
         complex128.  Returns ``self``; warns and returns ``None`` when the basis
         already carries spin."""
+        if is_sharded_module(self.np):
+            return sharded_basis.change_to_general_orbital_basis(self, a=a, b=b, anti_symmetrize=anti_symmetrize)
         if self._includes_spin:
             warnings.warn(
                 "The basis has already been spin-doubled. Avoiding a second doubling."
@@ -421,16 +460,27 @@ class BasisSet:
         d_h = kernels.add_spin_one_body(_stage(self.h), out_dtype=c128)
         d_s = kernels.add_spin_one_body(d_overlap, out_dtype=c128)
 
-        anti_now = bool(anti_symmetrize) and not self._anti_symmetrized_u
         old_u = self._u
         self._u = None
-        d_u = kernels.spin_expand_two_body(_stage(old_u), antisymmetrize=anti_now, out_dtype=c128)
+        fused = not self._statics_overridden() and len(old_u.shape) == 4
+        if fused:
+            # one read of the spatial tensor, one write of the 16x spin tensor: expansion, anti-symmetrisation
+            # (:605-606) and the complex cast (:634) in one kernel
+            anti_now = bool(anti_symmetrize) and not self._anti_symmetrized_u
+            d_u = kernels.spin_expand_two_body(_stage(old_u), antisymmetrize=anti_now, out_dtype=c128)
+            new_u = _deliver(d_u, np)
+            del d_u
+        else:
+            # a subclass's own expansion (ODSincDVR: kron(K, ones(2, 2)) of its 2-d u), as :576 does; the
+            # anti-symmetrisation follows below through self.anti_symmetrize_u
+            anti_now = False
+            new_u = self.add_spin_two_body(old_u, np=np)
         del old_u
 
         self.h = _deliver(d_h, np)
         self.s = _deliver(d_s, np)
-        self.u = _deliver(d_u, np)
-        del d_u
+        self.u = new_u
+        del new_u
 
         if getattr(self, "u_repr", "4d") != "2d":
             av = numpy.asarray(to_host(a)).astype(numpy.complex128).reshape(-1, 1)
@@ -456,7 +506,10 @@ class BasisSet:
             self._spin_2_tb_recipe = (_deliver(stack, np), anti_now)
 
         if anti_symmetrize:
-            self._anti_symmetrized_u = True
+            if fused:
+                self._anti_symmetrized_u = True       # done inside the expansion kernel (and the lazy spin_2_tb)
+            else:
+                self.anti_symmetrize_two_body_elements()                  # :605-606
 
         if self.position is not None:
             self.position = _deliver(

@@ -1,6 +1,8 @@
 """``GeneralOrbitalSystem``: matrix elements over general spin orbitals
 (reference: quantum_systems/general_orbital_system.py)."""
 
+from . import sharded_basis
+from .sharded_module import is_sharded
 from .system import QuantumSystem
 
 
@@ -34,6 +36,8 @@ class GeneralOrbitalSystem(QuantumSystem):
         h = self.h if h is None else h
         u = self.u if u is None else u
         np = self.np
+        if is_sharded(u):
+            return sharded_basis.compute_reference_energy(h, u, self.n, True, self.nuclear_repulsion_energy)
         return (
             np.trace(h[o, o])
             + 0.5 * np.trace(np.trace(u[o, o, o, o], axis1=1, axis2=3))
@@ -45,6 +49,8 @@ class GeneralOrbitalSystem(QuantumSystem):
         (general_orbital_system.py:123-159)."""
         np = self.np
         o = self.o
+        if is_sharded(u):
+            return sharded_basis.construct_fock_matrix(h, u, self.n, True, f=f)
         if f is None:
             f = np.zeros_like(h)
         f.fill(0)

@@ -39,14 +39,22 @@ from . import kernels
 
 
 class SlabPartition:
-    """Contiguous, balanced split of ``n`` rows over ``world`` ranks."""
+    """Contiguous split of ``n`` rows over ``world`` ranks: balanced by default, or the explicit
+    ``starts`` (world + 1 non-decreasing offsets from 0 to n) -- spin doubling turns the balanced split of
+    l spatial rows into twice those offsets, which is not the balanced split of 2l when l % world != 0."""
 
-    def __init__(self, n, world):
+    def __init__(self, n, world, starts=None):
         if world < 1 or n < 1:
             raise ValueError("need n >= 1 and world >= 1")
         self.n, self.world = int(n), int(world)
-        base, extra = divmod(self.n, self.world)
-        self.starts = [r * base + min(r, extra) for r in range(self.world + 1)]
+        if starts is None:
+            base, extra = divmod(self.n, self.world)
+            self.starts = [r * base + min(r, extra) for r in range(self.world + 1)]
+        else:
+            self.starts = [int(x) for x in starts]
+            if (len(self.starts) != self.world + 1 or self.starts[0] != 0 or self.starts[-1] != self.n
+                    or any(b < a for a, b in zip(self.starts, self.starts[1:]))):
+                raise ValueError(f"bad partition {self.starts} of {self.n} rows over {self.world} ranks")
 
     def bounds(self, rank):
         return self.starts[rank], self.starts[rank + 1]
@@ -54,6 +62,13 @@ class SlabPartition:
     def count(self, rank):
         lo, hi = self.bounds(rank)
         return hi - lo
+
+    def doubled(self):
+        """The partition of the 2n spin rows P = 2p + sigma that keeps every rank's rows together."""
+        return SlabPartition(2 * self.n, self.world, [2 * x for x in self.starts])
+
+    def is_balanced(self):
+        return self.starts == SlabPartition(self.n, self.world).starts
 
 
 class HipEngine:
@@ -76,6 +91,27 @@ class HipEngine:
         dimensions and batch strides in elements) -- ``qs_matmul`` as is."""
         return kernels.gemm_raw(dt, A, B, out, m, n, k, lda, ldb, ldc, batch, sa, sb, sc,
                                 accumulate, a_off, b_off, c_off)
+
+    # the slab-local operations behind a sharded BasisSet (sharded_basis.py)
+    @staticmethod
+    def transform_one_body(h, C, C_tilde):
+        return kernels.transform_one_body(h, C, C_tilde)
+
+    @staticmethod
+    def add_spin_one_body(h, out_dtype=None):
+        return kernels.add_spin_one_body(h, out_dtype=out_dtype)
+
+    @staticmethod
+    def spin_expand_block(u_block, antisymmetrize=False, out_dtype=None):
+        return kernels.spin_expand_two_body_block(u_block, antisymmetrize=antisymmetrize, out_dtype=out_dtype)
+
+    @staticmethod
+    def antisymmetrize(u_block, in_place=False):
+        return kernels.antisymmetrize(u_block, out=u_block if in_place else None)
+
+    @staticmethod
+    def spin_squared_two_body(S, antisymmetrize=False, p_lo=0, p_hi=None):
+        return kernels.spin_squared_two_body(S, antisymmetrize=antisymmetrize, p_lo=p_lo, p_hi=p_hi)
 
 
 def _bra(C, C_tilde):
@@ -105,12 +141,12 @@ def _as_real_flat(t):
     return t.reshape(-1)
 
 
-def all_gather_slabs(out_slab, M, rank, world, group=None, full=None):
+def all_gather_slabs(out_slab, M, rank, world, group=None, full=None, part=None):
     """Replicate the p-sharded result: returns the full (M,M,M,M) tensor (the single
     all-gather of the north star).  Even slabs are gathered straight into the result
     tensor (no staging copy); uneven slabs are padded to the largest.  ``full`` may
     supply the result buffer."""
-    part = SlabPartition(M, world)
+    part = part or SlabPartition(M, world)
     if world == 1:
         return out_slab
     per_row = M * M * M
@@ -119,7 +155,7 @@ def all_gather_slabs(out_slab, M, rank, world, group=None, full=None):
         full = torch.empty((M, M, M, M), dtype=out_slab.dtype, device=out_slab.device)
     full_flat = _as_real_flat(full)  # view of `full`
     flat = _as_real_flat(out_slab)
-    if M % world == 0:
+    if M % world == 0 and part.is_balanced():
         dist.all_gather_into_tensor(full_flat, flat, group=group)
         return full
     biggest = max(part.count(r) for r in range(world)) * per_row * width
@@ -135,7 +171,7 @@ def all_gather_slabs(out_slab, M, rank, world, group=None, full=None):
 
 
 def transform_two_body_sharded(u_bslab, C, C_tilde=None, rank=0, world=1, group=None,
-                               engine=HipEngine):
+                               engine=HipEngine, in_part=None):
     """p-slab of the transform from a ``u`` sharded over its second index.
 
     ``u_bslab = u[:, b_lo:b_hi, :, :]`` (contiguous) with the balanced split of
@@ -144,7 +180,7 @@ def transform_two_body_sharded(u_bslab, C, C_tilde=None, rank=0, world=1, group=
     """
     Ct = _bra(C, C_tilde)
     L, M = C.shape
-    bpart, ppart = SlabPartition(L, world), SlabPartition(M, world)
+    bpart, ppart = (in_part or SlabPartition(L, world)), SlabPartition(M, world)   # in_part: a non-balanced input split
     b_lo, b_hi = bpart.bounds(rank)
     bl = b_hi - b_lo
     if tuple(u_bslab.shape) != (L, bl, L, L):
@@ -199,6 +235,70 @@ def transform_two_body_sharded(u_bslab, C, C_tilde=None, rank=0, world=1, group=
         engine.matmul(Ct[:, g_lo:g_hi].contiguous(), recv_blocks[g], out=out, accumulate=not first)
         first = False
     return out.reshape(pc, M, M, M)
+
+
+def transform_two_body_sharded_a(u_aslab, C, C_tilde=None, rank=0, world=1, group=None,
+                                 engine=HipEngine, in_part=None):
+    """The mirror image of ``transform_two_body_sharded``: ``u`` sharded over its LEADING index
+    (``u_aslab = u[a_lo:a_hi]``, the layout every slab-local producer leaves behind) -> the result sharded
+    over its SECOND index, ``out[:, q_lo:q_hi]`` of shape (M, ql, M, M).
+
+    d, c and b are contracted on the slab (``qs_transform_two_body_partial``: rows of the leading index
+    are independent there), ONE all-to-all re-shards ``[a_loc, q] -> [a, q_loc]`` -- the same
+    (G-1)/G^2 l^4 elements per rank as the other layout -- and the contraction over a closes on the
+    received slabs.  A transform therefore flips which of the two leading indices is the sharded one;
+    every consumer on the path (anti-symmetrisation, spin doubling, Fock matrix, reference energy, the
+    next transform) works on either."""
+    Ct = _bra(C, C_tilde)
+    L, M = C.shape
+    apart, qpart = (in_part or SlabPartition(L, world)), SlabPartition(M, world)
+    a_lo, a_hi = apart.bounds(rank)
+    al = a_hi - a_lo
+    if tuple(u_aslab.shape) != (al, L, L, L):
+        raise ValueError(f"rank {rank}: slab shape {tuple(u_aslab.shape)}, expected {(al, L, L, L)}")
+    dt = kernels.result_dtype(u_aslab, C, Ct)
+    u_aslab, C, Ct = u_aslab.to(dt), C.to(dt), Ct.to(dt)
+    width = 2 if dt.is_complex else 1
+    q_lo, q_hi = qpart.bounds(rank)
+    ql = q_hi - q_lo
+    MM = M * M
+
+    # d, c, b on the slab:  v[a_loc, q, r, s]
+    v = engine.partial(u_aslab.contiguous(), C, Ct) if al > 0 else u_aslab.new_empty((0, M, M, M), dtype=dt)
+
+    if world == 1:
+        recv_blocks = [v.reshape(al, M * MM)]
+    else:
+        # one all-to-all: columns q of v go to the owner of q.  Packed per destination g as
+        # [a_loc][q in slab(g)][(r, s)]; from source g we receive [a in slab(g)][q_loc][(r, s)]
+        send = torch.cat([v[:, qpart.bounds(g)[0]:qpart.bounds(g)[1]].reshape(-1) for g in range(world)])
+        send = _as_real_flat(send)
+        in_splits = [al * qpart.count(g) * MM * width for g in range(world)]
+        out_splits = [apart.count(g) * ql * MM * width for g in range(world)]
+        recv = torch.empty(sum(out_splits), dtype=torch.float64, device=send.device)
+        del v
+        dist.all_to_all_single(recv, send, out_splits, in_splits, group=group)
+        del send
+        recv_blocks, off = [], 0
+        for g in range(world):
+            blk = recv[off: off + out_splits[g]]
+            off += out_splits[g]
+            if width == 2:
+                blk = torch.view_as_complex(blk.reshape(-1, 2))
+            recv_blocks.append(blk.reshape(apart.count(g), ql * MM))
+
+    # a:  out[p, (q_loc, r, s)] = sum_g Ct[p, a in slab(g)] R_g[a, (q_loc, r, s)]
+    out = torch.empty((M, ql * MM), dtype=dt, device=u_aslab.device)
+    if ql == 0:
+        return out.reshape(M, 0, M, M)
+    first = True
+    for g in range(world):
+        g_lo, g_hi = apart.bounds(g)
+        if g_hi == g_lo:
+            continue
+        engine.matmul(Ct[:, g_lo:g_hi].contiguous(), recv_blocks[g], out=out, accumulate=not first)
+        first = False
+    return out.reshape(M, ql, M, M)
 
 
 def transform_two_body_sharded_inplace(u_bslab, C, C_tilde=None, rank=0, world=1, group=None,
@@ -323,11 +423,12 @@ def fock_rows(h, u_slab, n_occ, p_lo, spin_orbitals=False):
     return f + 2 * direct - torch.einsum("piiq->pq", u_slab[:, o, o, :])
 
 
-def construct_fock_matrix_sharded(h, u_slab, n_occ, rank=0, world=1, spin_orbitals=False, group=None):
+def construct_fock_matrix_sharded(h, u_slab, n_occ, rank=0, world=1, spin_orbitals=False, group=None,
+                                  part=None):
     """Full Fock matrix on every rank from a p-sharded ``u``: slab-local rows,
     then one all-gather of l*l numbers."""
     l = h.shape[0]
-    part = SlabPartition(l, world)
+    part = part or SlabPartition(l, world)
     lo, hi = part.bounds(rank)
     if tuple(u_slab.shape[:1]) != (hi - lo,):
         raise ValueError(f"rank {rank}: slab has {u_slab.shape[0]} rows, expected {hi - lo}")
@@ -389,3 +490,49 @@ def reference_energy_sharded(h, u_slab, n_occ, rank=0, world=1, spin_orbitals=Fa
         total = torch.view_as_complex(buf.reshape(1, 2))[0]
         part = total if u_slab.is_complex() else total.real
     return part + nuclear_repulsion_energy
+
+
+def fock_partial_second_index(u_bslab, n_occ, b_lo, spin_orbitals=False):
+    """This rank's share of the two-body part of the Fock matrix when ``u`` is sharded over its SECOND
+    index (``u_bslab = u[:, b_lo:b_hi]``): the sums over the occupied i run over the second index,
+    so each rank adds the terms of its own occupied i and the shares add up (one all-reduce of l*l)."""
+    L = u_bslab.shape[0]
+    i_lo, i_hi = min(b_lo, n_occ), min(b_lo + u_bslab.shape[1], n_occ)
+    f = torch.zeros((L, L), dtype=u_bslab.dtype, device=u_bslab.device)
+    if i_hi > i_lo:
+        loc = slice(i_lo - b_lo, i_hi - b_lo)
+        direct = torch.einsum("piqi->pq", u_bslab[:, loc, :, i_lo:i_hi])
+        if spin_orbitals:
+            return f + direct
+        return f + 2 * direct - torch.einsum("piiq->pq", u_bslab[:, loc, i_lo:i_hi, :])
+    return f
+
+
+def reference_energy_partial_second_index(h, u_bslab, n_occ, b_lo, spin_orbitals=False):
+    """Share of the reference energy held by a second-index slab ``u[:, b_lo:b_hi]``: the terms
+    u_ijij / u_ijji whose j lies in the slab, plus the one-body terms h_jj of those j."""
+    j_lo, j_hi = min(b_lo, n_occ), min(b_lo + u_bslab.shape[1], n_occ)
+    o = slice(0, n_occ)
+    part = torch.zeros((), dtype=u_bslab.dtype, device=u_bslab.device)
+    if j_hi > j_lo:
+        loc = slice(j_lo - b_lo, j_hi - b_lo)
+        coul = torch.einsum("ijij->", u_bslab[o, loc, o, j_lo:j_hi])
+        hd = torch.diagonal(h)[j_lo:j_hi].sum().to(u_bslab.dtype)
+        if spin_orbitals:
+            part = hd + 0.5 * coul
+        else:
+            part = 2 * hd + 2 * coul - torch.einsum("ijji->", u_bslab[o, loc, j_lo:j_hi, o])
+    return part
+
+
+def all_reduce_sum(t, world, group=None):
+    """Sum of a (small) tensor over the ranks; complex values travel as interleaved pairs."""
+    if world == 1:
+        return t
+    if t.is_complex():
+        buf = torch.view_as_real(t.contiguous()).contiguous()
+        dist.all_reduce(buf, group=group)
+        return torch.view_as_complex(buf)
+    buf = t.contiguous()
+    dist.all_reduce(buf, group=group)
+    return buf

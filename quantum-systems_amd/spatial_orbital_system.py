@@ -3,7 +3,9 @@
 
 import copy
 
+from . import sharded_basis
 from .general_orbital_system import GeneralOrbitalSystem
+from .sharded_module import is_sharded
 from .system import QuantumSystem
 
 
@@ -30,9 +32,20 @@ class SpatialOrbitalSystem(QuantumSystem):
         alpha and a beta spin orbital, ``2n`` occupied, two-body elements
         anti-symmetrised by default.  This system is left intact
         (spatial_orbital_system.py:52-104)."""
-        gos = GeneralOrbitalSystem(
-            self.n * 2, self._basis_set.copy_basis(), a=a, b=b, anti_symmetrize=anti_symmetrize
-        )
+        # The reference deep-copies the whole basis set first (spatial_orbital_system.py:89-91,
+        # basis_set.py:784-805) so that this system stays intact.  The spin doubling never modifies the
+        # spatial ``u`` -- it reads it and writes the 16x larger spin tensor -- so the copy of ``u`` (34 GB at
+        # l = 256, and the one thing that does not fit when ``u`` is sharded over the node) is elided: the
+        # copy shares the tensor, everything O(l^2) is copied as upstream.
+        bs = self._basis_set
+        u = bs._u
+        bs._u = None
+        try:
+            twin = bs.copy_basis()
+        finally:
+            bs._u = u
+        twin._u = u
+        gos = GeneralOrbitalSystem(self.n * 2, twin, a=a, b=b, anti_symmetrize=anti_symmetrize)
         if self._time_evolution_operator is not None:
             gos.set_time_evolution_operator(copy.deepcopy(self._time_evolution_operator))
         return gos
@@ -44,6 +57,8 @@ class SpatialOrbitalSystem(QuantumSystem):
         np = self.np
         h = self.h if h is None else h
         u = self.u if u is None else u
+        if is_sharded(u):       # slab-local sums + one all-reduce of a single number
+            return sharded_basis.compute_reference_energy(h, u, self.n, False, self.nuclear_repulsion_energy)
         return (
             2 * np.trace(h[o, o])
             + 2 * np.trace(np.trace(u[o, o, o, o], axis1=1, axis2=3))
@@ -56,6 +71,8 @@ class SpatialOrbitalSystem(QuantumSystem):
         f_pq = h_pq + 2 u_piqi - u_piiq (spatial_orbital_system.py:152-190)."""
         np = self.np
         o = self.o
+        if is_sharded(u):       # slab-local rows / partial sums + l*l numbers over the node
+            return sharded_basis.construct_fock_matrix(h, u, self.n, False, f=f)
         if f is None:
             f = np.zeros_like(h)
         f.fill(0)
