@@ -368,6 +368,31 @@ def case_odqd():
          u_ctilde_as=dvr.transform_two_body_elements(dvr.u, C, np, anti_symmetrize=True, C_tilde=Ct))
 
 
+def case_sinc_dvr_spin():
+    """ODSincDVR with its 2-d u through the spin doubling (the only upstream route to a spin DVR basis):
+    add_spin_two_body / anti_symmetrize_u are overridden there (sinc_dvr.py:200-215) and
+    change_to_general_orbital_basis reaches them through self (basis_set.py:576, :523)."""
+    from quantum_systems.sinc_dvr.one_dim.sinc_dvr import ODSincDVR
+
+    out = {}
+    for tag, anti in (("as", True), ("noas", False)):
+        dvr = ODSincDVR(6, 4.0, potential=ODSincDVR.HOPotential(0.5))
+        assert dvr.u.shape == (6, 6)
+        ret = dvr.change_to_general_orbital_basis(anti_symmetrize=anti)
+        assert ret is dvr
+        out[tag + "_u"] = dvr.u
+        out[tag + "_h"], out[tag + "_s"] = dvr.h, dvr.s
+        out[tag + "_position"], out[tag + "_spf"] = dvr.position, dvr.spf
+        out[tag + "_flags"] = np.array([dvr.includes_spin, dvr.anti_symmetrized_u, dvr.spin_2_tb is None])
+    # includes_spin=True at construction, then the explicit driver call on the 2-d u: K stays K
+    dvr = ODSincDVR(6, 4.0, potential=ODSincDVR.HOPotential(0.5), includes_spin=True)
+    out["spin_ctor_u_before"] = dvr.u.copy()
+    dvr.anti_symmetrize_two_body_elements()
+    out["spin_ctor_u_after"] = dvr.u.copy()
+    out["spin_ctor_l"] = np.int64(dvr.l)
+    save("sinc_dvr_spin_doubling", **out)
+
+
 def case_tdho_one_body():
     """One-body side of the 2-D dots from the reference's own functions: double-well Hamiltonians,
     the orbital table and dipole elements of a small oscillator (the class methods are run on a bare
@@ -482,6 +507,9 @@ def case_fock_energy():
 
 
 if __name__ == "__main__":
+    if len(sys.argv) > 1 and sys.argv[1] == "sincspin":
+        case_sinc_dvr_spin()
+        sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "fock":
         case_fock_energy()
         sys.exit(0)
@@ -504,3 +532,4 @@ if __name__ == "__main__":
     case_odqd()
     case_tdho_one_body()
     case_fock_energy()
+    case_sinc_dvr_spin()

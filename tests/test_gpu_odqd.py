@@ -137,6 +137,39 @@ def test_sinc_dvr_change_basis_like_reference():
         d4.transform_two_body_elements(d4.u, C, np, anti_symmetrize=True)
 
 
+def test_sinc_dvr_spin_doubling_of_the_2d_form_like_reference():
+    # The only upstream route to a spin DVR basis: ODSincDVR(2-d u).change_to_general_orbital_basis goes
+    # through the class's OWN add_spin_two_body (kron(K, ones(2, 2))) and anti_symmetrize_u (identity on a
+    # matrix), reached via self as basis_set.py:576 / :523 do -- not through the rank-4 kernels.  Golden
+    # vectors from the reference class (tests/golden/make_golden.py: case_sinc_dvr_spin)
+    import quantum_systems_amd as qsa
+
+    g = np.load(os.path.join(GOLD, "sinc_dvr_spin_doubling.npz"))
+    for tag, anti in (("as", True), ("noas", False)):
+        dvr = qsa.ODSincDVR(6, 4.0, potential=qsa.ODSincDVR.HOPotential(0.5))
+        assert H(dvr.u).shape == (6, 6)
+        assert dvr.change_to_general_orbital_basis(anti_symmetrize=anti) is dvr
+        assert dvr.l == 12 and H(dvr.u).shape == (12, 12) and H(dvr.u).dtype == np.complex128
+        assert np.array_equal(H(dvr.u), g[tag + "_u"])                  # kron(K, ones(2,2)), never K - K^T
+        for k in ("h", "s", "position", "spf"):
+            np.testing.assert_allclose(H(getattr(dvr, k)), g[tag + "_" + k], rtol=1e-13, atol=1e-13)
+        flags = [dvr.includes_spin, dvr.anti_symmetrized_u, dvr.spin_2_tb is None]
+        assert flags == list(g[tag + "_flags"])
+    # a spin-carrying DVR basis handed the driver directly: the 2-d interaction is left alone (upstream
+    # anti_symmetrize_u returns the matrix unchanged), not replaced by K - K^T = 0
+    dvr = qsa.ODSincDVR(6, 4.0, potential=qsa.ODSincDVR.HOPotential(0.5), includes_spin=True)
+    assert np.array_equal(H(dvr.u), g["spin_ctor_u_before"])
+    dvr.anti_symmetrize_two_body_elements()
+    assert dvr.anti_symmetrized_u and np.array_equal(H(dvr.u), g["spin_ctor_u_after"])
+    assert np.abs(H(dvr.u)).max() > 0
+    # the 4-d representation takes the same route through the class's statics and agrees with the oracle
+    d4 = qsa.ODSincDVR(6, 4.0, potential=qsa.ODSincDVR.HOPotential(0.5), u_repr="4d")
+    u4 = H(d4.u).copy()
+    d4.change_to_general_orbital_basis(anti_symmetrize=True)
+    ref = orc.anti_symmetrize_u(orc.add_spin_two_body(u4)).astype(np.complex128)
+    assert np.array_equal(H(d4.u), ref) and d4.anti_symmetrized_u
+
+
 def test_spin_squared_like_reference():
     # tests/test_spin.py:136-177 (the part of the reference test that is active): singlet / triplet
     # expectation values of the two-spin S^2 built from the spinors stored on the spin-doubled ODQD basis;
