@@ -232,8 +232,9 @@ const char* qs_last_dispatch(void);
  *     "gemm_stream" (0 = never use the small-coefficient streaming kernel,
  *     2 = never split the rows of A over two waves), "slab_pair" (0 = never fuse
  *     the d and c contractions of a small-basis transform into one pass, 2 = one
- *     wave per slab always), "slab_ba" (0 = never fuse the b and a contractions
- *     of a small-basis transform).
+ *     wave per slab always), "sandwich" (the two fused passes of a small-basis
+ *     transform on the 4-wide fp64 matrix instruction: 0 = off, 1 = both,
+ *     2 = the (d, c) pass only, 3 = the (b, a) pass only).
  *   qs_probe_mfma_f64: register-resident fp64 MFMA loop, `blocks` workgroups
  *     of 4 waves, each wave issuing iters*8 v_mfma_f64_16x16x4_f64
  *     (flops = blocks*4*iters*8*2048); `sink` is a device scratch of

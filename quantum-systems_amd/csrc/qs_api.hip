@@ -137,8 +137,12 @@ static inline char* at(void* base, int64_t elems, size_t es) { return (char*)bas
 static int contract_dcb(int dtype, const void* u, const void* C, void* CT, const void* Ct,
                         void* T1, void* T2, void* T3, int64_t rows, int64_t L, int64_t M,
                         hipStream_t s) {
-    // small bases: d and c in one pass over the tensor (each slab u[a, b] is contiguous)
-    int rc = slab_pair_try(dtype, u, C, T2, rows * L, L, M, s);
+    // small bases: d and c in one pass over the tensor (each slab u[a, b] is contiguous):
+    //   T2[ab] = C^T . u[ab] . C   on the 4-wide matrix instruction, else on the 16-wide one
+    int rc = 1;
+    if (g_tune.sandwich == 1 || g_tune.sandwich == 2)
+        rc = sandwich4_try(dtype, u, T2, C, M, 1, C, 1, M, rows * L, L, M, L * L, L, 1, M * M, M, 1, s);
+    if (rc == 1) rc = slab_pair_try(dtype, u, C, T2, rows * L, L, M, s);
     if (rc == 1) {
         rc = transpose_small(dtype, C, CT, L, M, s);
         if (rc) return rc;
@@ -192,7 +196,7 @@ int qs_tuning_set(const char* key, int64_t value) {
     if (!strcmp(key, "slab_pair")) { g_tune.slab_pair = (int)value; return QS_OK; }
     if (!strcmp(key, "gemm_fast_persist")) { g_tune.gemm_fast_persist = (int)value; return QS_OK; }
     if (!strcmp(key, "gemm_fast_shape")) { g_tune.gemm_fast_shape = (int)value; return QS_OK; }
-    if (!strcmp(key, "slab_ba")) { g_tune.slab_ba = (int)value; return QS_OK; }
+    if (!strcmp(key, "sandwich")) { g_tune.sandwich = (int)value; return QS_OK; }
     return QS_ERR_BAD_EXTENT;
 }
 
@@ -235,6 +239,36 @@ int qs_transform_two_body(int dtype, const void* u, const void* C, const void* C
     void* WA = at(work, even_up(L * M), es);
     const int64_t wa = (L * L * L * M > L * M * M * M) ? L * L * L * M : L * M * M * M;
     void* WB = (M < L) ? at(WA, wa, es) : out;
+
+    // small bases: two passes over the tensor instead of four -- (d, c) per slab u[a, b], then (b, a) per
+    // column (r, s): out[:, :, rs] = Ct . T2[:, :, rs] . Ct^T (the same k-ordered sums, element for element)
+    if (g_tune.sandwich == 1 || g_tune.sandwich == 3) {
+        // T2 (L, L, M, M) goes to WA; the eligibility of the second pass is known before the first runs
+        const int64_t MM = M * M;
+        const bool second_ok = dtype == QS_F64 && L <= 64 && M <= 64 && cdiv(L, 4) == cdiv(M, 4) && cdiv(L, 4) >= 6 &&
+                               MM >= 1024 && (4 * cdiv(L, 4)) * L * MM * 2 * 8 < (int64_t(1) << 31);
+        if (second_ok) {
+            void* T1s = (M < L) ? at(WA, wa, es) : out;     // scratch of the unfused fall-back of the first pass
+            int rc2 = 1;
+            if (g_tune.sandwich == 1)
+                rc2 = sandwich4_try(dtype, u, WA, C, M, 1, C, 1, M, L * L, L, M, L * L, L, 1, MM, M, 1, s);
+            if (rc2 == 1) {
+                // first pass on the 16-wide kernels (T1 in the spare buffer, T2 into WA)
+                rc2 = slab_pair_try(dtype, u, C, WA, L * L, L, M, s);
+                if (rc2 == 1) {
+                    rc2 = transpose_small(dtype, C, CT, L, M, s);
+                    if (rc2) return rc2;
+                    rc2 = gemm(dtype, u, C, T1s, L * L * L, M, L, L, M, M, 1, 0, 0, 0, s);
+                    if (rc2) return rc2;
+                    rc2 = gemm(dtype, CT, T1s, WA, M, M, L, L, M, M, L * L, 0, L * M, MM, s);
+                }
+            }
+            if (rc2) return rc2;
+            rc2 = sandwich4_try(dtype, WA, out, Ct, 1, L, Ct, L, 1, MM, L, M, 1, L * MM, MM, 1, M * MM, MM, s);
+            if (rc2 != 1) return rc2;
+            return QS_ERR_HIP;    // unreachable: the second pass was checked eligible above
+        }
+    }
 
     int rc = contract_dcb(dtype, u, C, CT, Ct, /*T1*/ WA, /*T2*/ WB, /*T3*/ WA, L, L, M, s);
     if (rc) return rc;

@@ -90,6 +90,12 @@ int gemm_stream_try(int dtype, const double* A, const double* B, double* C, int6
 int slab_pair_try(int dtype, const void* X, const void* B, void* Z, int64_t nslabs, int64_t L, int64_t M,
                   hipStream_t stream);
 
+// Fused pair of contractions on the 4-wide matrix instruction (qs_sandwich4.hip): Out_t = Lm . In_t . R for a batch
+// of L x L matrices with arbitrary element strides; L, M <= 64, ceil(L/4) == ceil(M/4).
+int sandwich4_try(int dtype, const void* in, void* out, const void* R, int64_t r_sk, int64_t r_sj, const void* Lm,
+                  int64_t l_sp, int64_t l_sa, int64_t nitems, int64_t L, int64_t M, int64_t in_item, int64_t in_row,
+                  int64_t in_col, int64_t out_item, int64_t out_row, int64_t out_col, hipStream_t stream);
+
 // Short-and-wide streaming product (qs_gemm_skinny.hip): same return convention.
 int gemm_skinny_try(int dtype, const double* A, const double* B, double* C, int64_t m, int64_t n,
                     int64_t k, int64_t lda, int64_t ldb, int64_t ldc, int64_t batch, int accumulate,
@@ -122,7 +128,7 @@ struct Tuning {
     int gemm_skinny = 1;         // 0 disables the short-and-wide streaming product
     int gemm_stream = 1;         // 0 disables the small-coefficient streaming product, 2 = never split rows over two waves
     int slab_pair = 1;           // 0 disables the fused (d, c) pass, 2 = one wave per slab always
-    int slab_ba = 1;             // 0 disables the fused (b, a) pass
+    int sandwich = 1;            // 4-wide fused passes of a small-basis transform: 0 off, 1 both (d, c) and (b, a), 2 (d, c) only, 3 (b, a) only
 };
 extern thread_local Tuning g_tune;
 

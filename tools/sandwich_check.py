@@ -1,0 +1,45 @@
+"""Small-basis transform: the two fused 4-wide passes (qs_sandwich4.hip) against the previous path
+(fused (d, c) on the 16-wide instruction + two streaming products), same process, alternating runs:
+bit-equality of the results and time per transform.   python tools/sandwich_check.py [l ...]"""
+import sys
+
+import numpy as np
+import torch
+
+sys.path.insert(0, ".")
+from quantum_systems_amd import kernels as K  # noqa: E402
+
+
+def timed(fn, reps=50):
+    fn(); torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        fn()
+    e1.record(); torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / reps * 1e3   # us
+
+
+ls = [int(a) for a in sys.argv[1:]] or [24, 32, 40, 48, 52, 55, 56, 60, 64]
+g = torch.Generator(device="cuda").manual_seed(3)
+for l in ls:
+    u = torch.rand((l,) * 4, dtype=torch.float64, device="cuda", generator=g) - 0.5
+    C, _ = torch.linalg.qr(torch.randn(l, l, dtype=torch.float64, device="cuda", generator=g))
+    C = C.contiguous(); Ct = C.t().contiguous()
+    out = {}
+    for mode in (0, 1, 2, 3):
+        K.tuning_set("sandwich", mode)
+        res = torch.empty_like(u)
+        K.transform_two_body(u, C, Ct, out=res)
+        disp = K.last_dispatch()
+        t = min(timed(lambda: K.transform_two_body(u, C, Ct, out=res)) for _ in range(3))
+        out[mode] = (res.clone(), t, disp)
+    K.tuning_reset()
+    ref = out[0][0]
+    flops = 8 * l**5
+    line = f"l={l:3d}"
+    for mode in (0, 1, 2, 3):
+        same = torch.equal(out[mode][0], ref)
+        line += f" | mode {mode}: {out[mode][1]:7.1f} us {flops / out[mode][1] / 1e6:5.1f} TF {'bit-equal' if same else 'DIFFERS ' + format((out[mode][0] - ref).abs().max().item(), '.1e')}"
+    print(line, flush=True)
+    print("      ", out[1][2], flush=True)
