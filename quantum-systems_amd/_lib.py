@@ -10,7 +10,8 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libqs_amd.so")
+# QS_AMD_LIB: development hook -- another build of the SAME library (kernel A/B runs inside one gpurun call)
+LIB_PATH = os.environ.get("QS_AMD_LIB") or os.path.join(_HERE, "libqs_amd.so")
 
 QS_F64 = 0
 QS_C128 = 1

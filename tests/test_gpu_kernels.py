@@ -544,6 +544,72 @@ def test_fused_dc_pass_keeps_non_finite_values_in_their_slabs(K):
     np.testing.assert_allclose(rest, ref, rtol=1e-11, atol=1e-11)
 
 
+# ------------------------- both halves of a small-basis transform on the 4-wide instruction (qs_sandwich4.hip)
+
+
+@pytest.mark.parametrize("L,M", [(32, 32), (33, 33), (36, 34), (40, 40), (41, 44), (47, 48), (50, 49), (53, 55),
+                                 (55, 55), (55, 53), (56, 56), (58, 60), (61, 64), (64, 64)])
+def test_sandwich_passes_bit_identical_to_the_16_wide_path(K, L, M):
+    # (d, c) per slab and (b, a) per column as Out = Lm . In . R on v_mfma_f64_4x4x4_4b_f64: four items per
+    # instruction, extents padded to 4 instead of 16, Y chained through the accumulators.  The sums are the same
+    # k-ordered FMA chains, so the transform is bit-identical to the 16-wide kernels' -- with the kernel forced
+    # wherever it is legal (sandwich = 4), in every work split, for each pass alone, and in the automatic choice
+    rng = np.random.default_rng(L * 100 + M)
+    u = rng.standard_normal((L,) * 4)
+    C = rng.standard_normal((L, M)) / np.sqrt(L)
+    Ct = rng.standard_normal((M, L)) / np.sqrt(L)
+    ref = orc.transform_two_body(u, C, Ct)
+    du, dC, dCt = dev(u), dev(C), dev(Ct)
+    with K.tuning(sandwich=0):
+        plain = host(K.transform_two_body(du, dC, dCt))
+        assert "sandwich4" not in K.last_dispatch()
+        plain_part = host(K.transform_two_body_partial(du[3:19], dC, dCt))
+    assert relerr(plain, ref) <= 1e-13
+    auto = host(K.transform_two_body(du, dC, dCt))
+    assert np.array_equal(auto, plain)
+    for knobs in (dict(sandwich=4), dict(sandwich=4, sandwich_mode=0), dict(sandwich=4, sandwich_mode=1),
+                  dict(sandwich=4, sandwich_mode=3), dict(sandwich=2), dict(sandwich=3)):
+        with K.tuning(**knobs):
+            got = host(K.transform_two_body(du, dC, dCt))
+            disp = K.last_dispatch()
+            part = host(K.transform_two_body_partial(du[3:19], dC, dCt))
+        assert np.array_equal(got, plain), knobs
+        assert np.array_equal(part, plain_part), knobs
+        if knobs.get("sandwich") == 4:
+            assert disp == f"qs::sandwich4_kernel<{-(-L // 4)}> x2", disp
+
+
+def test_sandwich_is_the_automatic_choice_for_config_2(K):
+    # BASELINE.json configs[1]: l = 55 -> two launches of the 4-wide kernel
+    g = torch.Generator(device="cuda:0").manual_seed(55)
+    u = torch.rand(55, 55, 55, 55, dtype=torch.float64, device="cuda:0", generator=g)
+    C, _ = torch.linalg.qr(torch.randn(55, 55, dtype=torch.float64, device="cuda:0", generator=g))
+    out = K.transform_two_body(u, C.contiguous())
+    assert K.last_dispatch() == "qs::sandwich4_kernel<14> x2"
+    ref = orc.transform_two_body(host(u), host(C))
+    assert relerr(host(out), ref) <= 1e-13
+
+
+def test_sandwich_pass_keeps_non_finite_values_in_their_slabs(K):
+    # the padded rows / columns / items of a quad are parked lanes (hardware zeros), never neighbouring data:
+    # a NaN at the start of slab (4, 0) and an Inf in slab (6, 0) stay in the slabs of a = 4 and a = 6
+    rng = np.random.default_rng(61)
+    L = 53
+    u = rng.standard_normal((L,) * 4)
+    C = rng.standard_normal((L, L)) / np.sqrt(L)
+    u[4, 0, 0, 0] = np.nan
+    u[6, 0, 0, 1] = np.inf
+    with K.tuning(sandwich=4):
+        got = host(K.transform_two_body_partial(dev(u[:9]), dev(C), dev(C.T.copy())))
+        assert "sandwich4" in K.last_dispatch()
+    clean = np.delete(u[:9], [4, 6], axis=0)
+    ref = orc.transform_two_body_dcb(clean, C, C.T.copy())
+    assert not np.isfinite(got[4]).any() and not np.isfinite(got[6]).any()
+    rest = np.delete(got, [4, 6], axis=0)
+    assert np.isfinite(rest).all()
+    np.testing.assert_allclose(rest, ref, rtol=1e-11, atol=1e-11)
+
+
 def test_replicated_layout_matches_full_transform(K):
     # sharded.transform_two_body_replicated on one GPU, every rank's slab (uses the skinny product)
     from quantum_systems_amd import sharded

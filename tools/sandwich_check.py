@@ -20,15 +20,19 @@ def timed(fn, reps=50):
     return e0.elapsed_time(e1) / reps * 1e3   # us
 
 
-ls = [int(a) for a in sys.argv[1:]] or [24, 32, 40, 48, 52, 55, 56, 60, 64]
+ls = [int(a) for a in sys.argv[1:]] or list(range(21, 65))
 g = torch.Generator(device="cuda").manual_seed(3)
 for l in ls:
     u = torch.rand((l,) * 4, dtype=torch.float64, device="cuda", generator=g) - 0.5
     C, _ = torch.linalg.qr(torch.randn(l, l, dtype=torch.float64, device="cuda", generator=g))
     C = C.contiguous(); Ct = C.t().contiguous()
     out = {}
-    for mode in (0, 1, 2, 3):
-        K.tuning_set("sandwich", mode)
+    MODES = (0, 1, 2, 3) if len(ls) > 8 else (0, 1, 2, 3, 10, 11, 13)
+    for mode in MODES:
+        if mode >= 10:
+            K.tuning_set("sandwich", 1); K.tuning_set("sandwich_mode", mode - 10)
+        else:
+            K.tuning_reset(); K.tuning_set("sandwich", mode)
         res = torch.empty_like(u)
         K.transform_two_body(u, C, Ct, out=res)
         disp = K.last_dispatch()
@@ -38,8 +42,9 @@ for l in ls:
     ref = out[0][0]
     flops = 8 * l**5
     line = f"l={l:3d}"
-    for mode in (0, 1, 2, 3):
+    for mode in MODES:
         same = torch.equal(out[mode][0], ref)
         line += f" | mode {mode}: {out[mode][1]:7.1f} us {flops / out[mode][1] / 1e6:5.1f} TF {'bit-equal' if same else 'DIFFERS ' + format((out[mode][0] - ref).abs().max().item(), '.1e')}"
     print(line, flush=True)
-    print("      ", out[1][2], flush=True)
+    best = min(MODES, key=lambda m: out[m][1])
+    print("       best mode", best, "|", out[1][2], flush=True)
