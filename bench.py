@@ -695,7 +695,7 @@ def run_rank(args):
         "vs_baseline": None, "dtype": args.dtype, "data": data,
         "config": {
             "workload": f"RandomBasisSet-shaped l={l} {args.dtype} four-index transform "
-                        f"(BASELINE.json configs[{2 if kf == 1 else 4}]), u resident in HBM, C unitary"
+                        f"(BASELINE.json configs[{(1 if l == 55 else 2) if kf == 1 else 4}]), u resident in HBM, C unitary"
                         + (", a new C every step (C_tilde derived inside the call)" if fresh_c else ""),
             "l": l, "flops_per_step": flops, "layout": layout,
             "frac_of_mfma_peak": value / (MFMA_F64_PEAK_TFLOPS * world),

@@ -240,9 +240,14 @@ __global__ __launch_bounds__(256, 1) void sandwich4_kernel(const S4Args g) {
     // One chunk: NJ column groups starting at jg0 for the item quad behind (rs_in, v_in); the ring already
     // holds row quads 0 and 1 of it.  While row quad ka multiplies, row quad ka + 2 is fetched -- of this item
     // quad, or (the last two) of the next one, behind (rs_pf, v_pf).  P = parity of the ring stage of ka = 0.
-    auto chunk = [&](auto NJC, auto PC, int jg0, auto rs_in, auto rs_out, const unsigned (&v_out)[4],
+    // ONE body serves chunks of NJ and of NJ - 1 column groups: the last group rides in two blocks of their own
+    // per step that a narrow chunk (full == false, wave-uniform) branches around.  Two bodies would leave the ring
+    // and the in-flight fetch registers in different physical registers, and the copies at the merge cost a
+    // drain to vmcnt(0) plus ~90 moves per unit.
+    auto chunk = [&](auto NJC, auto PC, int jg0, bool full, auto rs_in, auto rs_out, const unsigned (&v_out)[4],
                      auto rs_pf, const unsigned (&v_pf)[4], const unsigned (&v_in)[4]) __attribute__((always_inline)) {
         constexpr int NJ = decltype(NJC)::value, P = decltype(PC)::value;
+        constexpr int NJM = (NJ_BIG == NJ_SMALL) ? NJ : NJ - 1;      // groups every chunk has
         double bf[N4][NJ];
         unroll<0, N4>([&](auto KS) __attribute__((always_inline)) {
             unroll<0, NJ>([&](auto J) __attribute__((always_inline)) {
@@ -264,10 +269,12 @@ __global__ __launch_bounds__(256, 1) void sandwich4_kernel(const S4Args g) {
                 constexpr int j = decltype(J)::value;
                 const double val = acc2[pg][j];
                 const bool last_col = jg0 + j == N4 - 1;                  // wave-uniform
+                unsigned vo = last_col ? v_end : v_mid;
+                if (j >= NJM && !full) vo = kParked;                      // this chunk has no such group
                 if constexpr (QS_S4_ABLATE & 2) { if (val == 12345.678) my_transit[0] = val; }
                 else
-                __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, val), rs_out,
-                                                      (int)(last_col ? v_end : v_mid), (int)((jg0 + j) * jg_step), 0);
+                __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, val), rs_out, (int)vo,
+                                                      (int)((jg0 + j) * jg_step), 0);
             });
         };
         // Every memory instruction of a step rides between MFMAs (one k quad / one row quad of MFMAs carries at most
@@ -286,7 +293,7 @@ __global__ __launch_bounds__(256, 1) void sandwich4_kernel(const S4Args g) {
             double acc1[NJ];
             unroll<0, N4>([&](auto KS) __attribute__((always_inline)) {
                 constexpr int ks = decltype(KS)::value;
-                unroll<0, NJ>([&](auto J) __attribute__((always_inline)) {
+                unroll<0, NJM>([&](auto J) __attribute__((always_inline)) {
                     constexpr int j = decltype(J)::value;
                     acc1[j] = mfma4(ring[st][ks], bf[ks][j], ks == 0 ? 0.0 : acc1[j]);
                 });
@@ -296,13 +303,26 @@ __global__ __launch_bounds__(256, 1) void sandwich4_kernel(const S4Args g) {
                 else stg[st ^ 1][ks] = fetch_frag(rs_in, ks == N4 - 1 ? vf_end : vf_mid, KS);
                 __builtin_amdgcn_sched_barrier(0);
             });
+            if constexpr (NJM < NJ) {
+                if (full) {     // the last column group of a wide chunk: both products, no memory operation in between
+                    unroll<0, N4>([&](auto KS) __attribute__((always_inline)) {
+                        constexpr int ks = decltype(KS)::value;
+                        acc1[NJ - 1] = mfma4(ring[st][ks], bf[ks][NJ - 1], ks == 0 ? 0.0 : acc1[NJ - 1]);
+                    });
+                    unroll<0, N4>([&](auto PG) __attribute__((always_inline)) {
+                        constexpr int pg = decltype(PG)::value;
+                        acc2[pg][NJ - 1] = mfma4(lf[pg], acc1[NJ - 1], ka == 0 ? 0.0 : acc2[pg][NJ - 1]);
+                    });
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
             QS_S4_STAMP(64 + ka)
             // ---- Out[:][own columns] += Lm[:][ka rows] . Y[ka rows][own columns]   (Y straight from the accumulators);
             // meanwhile row quad ka + 1 comes back from the transit buffer in MFMA lane order, the Lm fragments of
             // row quad ka + 1 are read, and in the last step the finished rows of Out go out
             unroll<0, N4>([&](auto PG) __attribute__((always_inline)) {
                 constexpr int pg = decltype(PG)::value;
-                unroll<0, NJ>([&](auto J) __attribute__((always_inline)) {
+                unroll<0, NJM>([&](auto J) __attribute__((always_inline)) {
                     constexpr int j = decltype(J)::value;
                     acc2[pg][j] = mfma4(lf[pg], acc1[j], ka == 0 ? 0.0 : acc2[pg][j]);
                 });
@@ -373,22 +393,13 @@ __global__ __launch_bounds__(256, 1) void sandwich4_kernel(const S4Args g) {
         const int jg0 = chunk_first(c);
         const bool big = c < N_BIG;
         if constexpr (N4 % 2 == 0) {
-            if (big) chunk(std::integral_constant<int, NJ_BIG>{}, std::integral_constant<int, 0>{}, jg0, rs_in, rs_out,
-                           v_out, rs_nx, v_nx, v_in);
-            else chunk(std::integral_constant<int, NJ_SMALL>{}, std::integral_constant<int, 0>{}, jg0, rs_in, rs_out,
-                       v_out, rs_nx, v_nx, v_in);
+            chunk(std::integral_constant<int, NJ_BIG>{}, std::integral_constant<int, 0>{}, jg0, big, rs_in, rs_out, v_out,
+                  rs_nx, v_nx, v_in);
         } else {
-            if (big) {
-                if (parity) chunk(std::integral_constant<int, NJ_BIG>{}, std::integral_constant<int, 1>{}, jg0, rs_in,
-                                  rs_out, v_out, rs_nx, v_nx, v_in);
-                else chunk(std::integral_constant<int, NJ_BIG>{}, std::integral_constant<int, 0>{}, jg0, rs_in, rs_out,
-                           v_out, rs_nx, v_nx, v_in);
-            } else {
-                if (parity) chunk(std::integral_constant<int, NJ_SMALL>{}, std::integral_constant<int, 1>{}, jg0, rs_in,
-                                  rs_out, v_out, rs_nx, v_nx, v_in);
-                else chunk(std::integral_constant<int, NJ_SMALL>{}, std::integral_constant<int, 0>{}, jg0, rs_in,
-                           rs_out, v_out, rs_nx, v_nx, v_in);
-            }
+            if (parity) chunk(std::integral_constant<int, NJ_BIG>{}, std::integral_constant<int, 1>{}, jg0, big, rs_in,
+                              rs_out, v_out, rs_nx, v_nx, v_in);
+            else chunk(std::integral_constant<int, NJ_BIG>{}, std::integral_constant<int, 0>{}, jg0, big, rs_in, rs_out,
+                       v_out, rs_nx, v_nx, v_in);
             parity ^= 1;
         }
         unit = nu;
