@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define QS_ABI_VERSION 1
+#define QS_ABI_VERSION 2
 
 enum {
     QS_OK = 0,
@@ -44,7 +44,8 @@ enum {
     QS_ERR_WORKSPACE = -4,    /* workspace smaller than qs_*_workspace says  */
     QS_ERR_HIP = -5,          /* a HIP runtime call or kernel launch failed  */
     QS_ERR_BAD_DTYPE = -6,    /* dtype code not QS_F64 / QS_C128             */
-    QS_ERR_ALIAS = -7         /* output aliases an input where not allowed   */
+    QS_ERR_ALIAS = -7,        /* output aliases an input where not allowed   */
+    QS_ERR_COMM = -8          /* RCCL call failed / librccl not loadable     */
 };
 
 enum { QS_F64 = 0, QS_C128 = 1 };
@@ -204,6 +205,70 @@ int qs_tdho_coulomb_elements(void* out, int64_t l, int64_t p_lo, int64_t p_hi,
 int qs_tdho_coulomb_elements_nm(void* out, const void* nm_table, int64_t l,
                                 int64_t max_shell, int64_t p_lo, int64_t p_hi,
                                 void* stream);
+
+/*
+ * ---- several GPUs of one node: one process per GPU, RCCL over xGMI ------------
+ * (the reference itself knows one device only.)
+ *
+ * qs_comm_unique_id: 128 bytes that identify a communicator; ONE rank calls it,
+ *   the host distributes the bytes to the other ranks by its own means (MPI
+ *   broadcast, a file, a socket) -- exactly ncclGetUniqueId's contract.
+ * qs_comm_init: collective over the `world` ranks; binds the communicator to
+ *   the calling thread's current device and creates the stream the exchange
+ *   runs on.  The handle is the only persistent object the library owns.
+ * qs_comm_destroy: frees it.  qs_last_comm_error: text of the calling thread's
+ *   most recent QS_ERR_COMM.
+ * RCCL is loaded at run time (librccl.so.1; the copy already in the process
+ * when there is one): single-GPU users have no link-time dependency on it.
+ */
+#define QS_UNIQUE_ID_BYTES 128
+int qs_comm_unique_id(void* id /* QS_UNIQUE_ID_BYTES */);
+int qs_comm_init(void** comm, int rank, int world, const void* unique_id);
+int qs_comm_destroy(void* comm);
+int qs_comm_rank(void* comm);
+int qs_comm_world(void* comm);
+const char* qs_last_comm_error(void);
+
+/*
+ * Four-index transform of a tensor sharded over the ranks of `comm`:
+ *   u_bslab   : u[:, b_lo:b_hi, :, :]  (L, bl, L, L), this rank's share of the
+ *               SECOND index; balanced split: the first L % world ranks hold
+ *               L / world + 1 rows (same rule for the result)
+ *   out_pslab : out[p_lo:p_hi]  (pc, M, M, M), this rank's share of the LEADING
+ *               index of the result
+ *   C (L, M), Ct (M, L) replicated on every rank.
+ * d, c and a are contracted on the slab, ONE exchange re-shards
+ * [p, b_loc] -> [p_loc, b] -- (world-1)/world^2 of the tensor leaves every rank,
+ * as grouped ncclSend / ncclRecv pairs so that every peer's xGMI link carries
+ * its share at once -- and the contraction over b closes on the received rows.
+ * The exchange is issued in `nchunks` pieces (1..16; <= 0 selects 4) on the
+ * communicator's stream and overlaps the products on `stream`; on return,
+ * `stream` is ordered behind all of it.  Replaces transform_two_body_elements
+ * (basis_set.py:336-350) for a tensor that one device does not hold;
+ * collective: every rank of `comm` must call it with the same L, M, nchunks.
+ */
+int64_t qs_transform_two_body_sharded_workspace(int dtype, int64_t L, int64_t M,
+                                                int world, int rank);
+int qs_transform_two_body_sharded(void* comm, int dtype, const void* u_bslab,
+                                  const void* C, const void* Ct, void* out_pslab,
+                                  void* work, int64_t work_bytes, int64_t L,
+                                  int64_t M, int nchunks, void* stream);
+
+/*
+ * The exchange plan of qs_transform_two_body_sharded for one rank, as numbers
+ * (pure index arithmetic: no GPU, no RCCL).  Test hook: the CPU suite replays
+ * the plans of all ranks of a world with NumPy and checks that every row ends
+ * up where the closing product reads it.
+ *   header  : {b_lo, bl, p_lo, pc, row_x, row_r, nchunks}
+ *   ct_rows : M entries, the row of Ct multiplied in slot i of X
+ *   chunks  : nchunks x {first slot, slots, first result row (relative), result rows}
+ *   table   : one row {chunk, peer, kind, x_off, r_off, count, rows} per
+ *             operation, kind 0 send / 1 receive / 2 own rows (X -> R)
+ * Returns the number of operations (<= table_rows) or a negative QS_ERR_*.
+ */
+int qs_sharded_exchange_plan(int64_t L, int64_t M, int world, int rank,
+                             int nchunks, int64_t* header, int64_t* ct_rows,
+                             int64_t* chunks, int64_t* table, int64_t table_rows);
 
 /*
  * Which kernels the calling thread's most recent compute entry point launched,

@@ -43,6 +43,16 @@ SIGNATURES = {
     "qs_spin_squared_two_body": (c_int, [c_ptr, c_ptr, c_i64, c_i64, c_i64, c_int, c_ptr]),
     "qs_tdho_coulomb_elements": (c_int, [c_ptr, c_i64, c_i64, c_i64, c_ptr]),
     "qs_tdho_coulomb_elements_nm": (c_int, [c_ptr, c_ptr, c_i64, c_i64, c_i64, c_i64, c_ptr]),
+    "qs_comm_unique_id": (c_int, [c_ptr]),
+    "qs_comm_init": (c_int, [ctypes.POINTER(c_ptr), c_int, c_int, c_ptr]),
+    "qs_comm_destroy": (c_int, [c_ptr]),
+    "qs_comm_rank": (c_int, [c_ptr]),
+    "qs_comm_world": (c_int, [c_ptr]),
+    "qs_last_comm_error": (ctypes.c_char_p, []),
+    "qs_transform_two_body_sharded_workspace": (c_i64, [c_int, c_i64, c_i64, c_int, c_int]),
+    "qs_transform_two_body_sharded": (
+        c_int, [c_ptr, c_int, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_i64, c_i64, c_i64, c_int, c_ptr]),
+    "qs_sharded_exchange_plan": (c_int, [c_i64, c_i64, c_int, c_int, c_int, c_ptr, c_ptr, c_ptr, c_ptr, c_i64]),
     "qs_last_dispatch": (ctypes.c_char_p, []),
     "qs_tuning_set": (c_int, [ctypes.c_char_p, c_i64]),
     "qs_tuning_reset": (c_int, []),
@@ -50,7 +60,7 @@ SIGNATURES = {
     "qs_probe_stream_copy": (c_int, [c_ptr, c_ptr, c_i64, c_ptr]),
 }
 
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 
 class QsLibraryError(RuntimeError):
@@ -98,6 +108,8 @@ def check(code, what):
     msg = lib.qs_error_string(int(code)).decode()
     if code == -5:
         msg += " (" + lib.qs_last_hip_error().decode() + ")"
+    if code == -8:
+        msg += " (" + lib.qs_last_comm_error().decode() + ")"
     if code in (-1, -3, -6, -7):
         # the same user mistakes raise AssertionError in the reference's
         # setters (basis_set.py:93,103,113); a wrong extent is a ValueError

@@ -172,6 +172,7 @@ const char* qs_error_string(int code) {
         case QS_ERR_HIP: return "HIP runtime error";
         case QS_ERR_BAD_DTYPE: return "unsupported dtype code";
         case QS_ERR_ALIAS: return "output aliases an input";
+        case QS_ERR_COMM: return "RCCL error";
         default: return "unknown error code";
     }
 }

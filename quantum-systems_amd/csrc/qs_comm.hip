@@ -1,0 +1,403 @@
+// Multi-GPU entry points of the C ABI (include/qs_amd.h): an RCCL communicator behind an opaque handle and the
+// four-index transform of a tensor sharded over the GPUs of one node, one process per GPU.
+//
+// The reference has no notion of a second device; SURVEY 8(b)/(e) asks for these entry points so that a
+// host that is not Python can shard the path.  Layout (the one sharded.transform_two_body_sharded uses): `u` is
+// sharded over its SECOND index (rank g holds u[:, b_lo:b_hi, :, :], balanced split), the result over its LEADING
+// index (rank g gets out[p_lo:p_hi]).
+//
+//   local      d, c, then a (local in this layout):  X[p, b_loc, r, s] = Ct[p,a] u[a,b,c,d] C[c,r] C[d,s]
+//   exchange   row p of X goes to the owner of p: (G-1)/G^2 of the tensor leaves every rank, one xGMI link per peer
+//   close      out[p_loc][q, (r,s)] = Ct[q, b] R[p_loc][b, (r,s)]   with R[p_loc] = the rows received for p_loc
+//
+// RCCL is used directly: grouped ncclSend / ncclRecv pairs, one pair per row and peer, so that all seven links of a
+// rank carry traffic at once (a ring all-to-all would be bound by one link).  The exchange is CHUNKED and runs on the
+// communicator's own stream: the rows of Ct are taken in an order in which every chunk holds rows of EVERY peer;
+// while chunk c travels, the contraction over a of chunk c + 1 and the closing contraction of chunk c - 1 run on the
+// caller's stream.  No packing anywhere: a row of X is one contiguous message, and it lands at its final place
+// R[p_loc][b_lo(sender) ...], from where the closing product reads it with K = L in one batched GEMM per chunk.
+//
+// RCCL is loaded at run time (dlopen of librccl.so.1: the copy PyTorch has already loaded when there is one), so the
+// single-GPU library has no link-time dependency on it.
+
+#include <dlfcn.h>
+#include <stdio.h>
+#include <string.h>
+
+#include "qs_common.h"
+
+namespace qs {
+
+namespace {
+
+// ---- the few RCCL symbols used, resolved once per process (the functions are process-wide facts, not state)
+typedef void* nccl_comm_t;
+struct NcclUniqueId { char internal[QS_UNIQUE_ID_BYTES]; };
+typedef int (*fn_get_unique_id)(NcclUniqueId*);
+typedef int (*fn_comm_init_rank)(nccl_comm_t*, int, NcclUniqueId, int);
+typedef int (*fn_comm_destroy)(nccl_comm_t);
+typedef int (*fn_group)(void);
+typedef int (*fn_send)(const void*, size_t, int, int, nccl_comm_t, hipStream_t);
+typedef int (*fn_recv)(void*, size_t, int, int, nccl_comm_t, hipStream_t);
+typedef const char* (*fn_error_string)(int);
+constexpr int kNcclFloat64 = 8;      // ncclFloat64 (rccl.h); complex128 travels as pairs of doubles
+
+struct Rccl {
+    void* handle = nullptr;
+    fn_get_unique_id get_unique_id = nullptr;
+    fn_comm_init_rank comm_init_rank = nullptr;
+    fn_comm_destroy comm_destroy = nullptr;
+    fn_group group_start = nullptr, group_end = nullptr;
+    fn_send send = nullptr;
+    fn_recv recv = nullptr;
+    fn_error_string error_string = nullptr;
+    bool ok = false;
+};
+
+static thread_local char g_comm_err[256] = "";
+
+const Rccl& rccl() {
+    static const Rccl lib = [] {
+        Rccl r;
+        const char* names[] = {"librccl.so.1", "librccl.so"};
+        for (const char* n : names) {      // a copy that is already in the process (PyTorch's) first
+            r.handle = dlopen(n, RTLD_NOW | RTLD_NOLOAD);
+            if (r.handle) break;
+        }
+        for (const char* n : names) {
+            if (r.handle) break;
+            r.handle = dlopen(n, RTLD_NOW | RTLD_LOCAL);
+        }
+        if (!r.handle) return r;
+        r.get_unique_id = (fn_get_unique_id)dlsym(r.handle, "ncclGetUniqueId");
+        r.comm_init_rank = (fn_comm_init_rank)dlsym(r.handle, "ncclCommInitRank");
+        r.comm_destroy = (fn_comm_destroy)dlsym(r.handle, "ncclCommDestroy");
+        r.group_start = (fn_group)dlsym(r.handle, "ncclGroupStart");
+        r.group_end = (fn_group)dlsym(r.handle, "ncclGroupEnd");
+        r.send = (fn_send)dlsym(r.handle, "ncclSend");
+        r.recv = (fn_recv)dlsym(r.handle, "ncclRecv");
+        r.error_string = (fn_error_string)dlsym(r.handle, "ncclGetErrorString");
+        r.ok = r.get_unique_id && r.comm_init_rank && r.comm_destroy && r.group_start && r.group_end && r.send &&
+               r.recv && r.error_string;
+        return r;
+    }();
+    return lib;
+}
+
+int rccl_status(int code, const char* what) {
+    if (code == 0) return QS_OK;
+    snprintf(g_comm_err, sizeof(g_comm_err), "%s: %s", what, rccl().error_string ? rccl().error_string(code) : "?");
+    return QS_ERR_COMM;
+}
+
+constexpr int kMaxChunks = 16;
+
+// balanced split of n rows over `world` ranks: the same rule as sharded.SlabPartition
+inline int64_t part_lo(int64_t n, int world, int r) {
+    const int64_t base = n / world, extra = n % world;
+    return r * base + (r < extra ? r : extra);
+}
+
+// ---- the exchange plan: pure index arithmetic, shared by the executor below and by qs_sharded_exchange_plan (which
+// lets a CPU test replay the plan of every rank with NumPy and check that the rows end up where the closing product
+// reads them -- the part of this file that a one-GPU box cannot exercise with more than one rank)
+struct PlanOp {
+    int chunk, peer, kind;         // kind 0 = send (offset into X), 1 = receive (offset into R), 2 = own rows X -> R
+    int64_t x_off, r_off, count;   // element offsets / count (own rows: count per row, `rows` rows, pitches below)
+    int64_t rows;
+};
+struct Plan {
+    int64_t b_lo, bl, p_lo, pc, row_x, row_r;       // row_x = bl*M*M elements of an X row, row_r = L*M*M of an R row
+    int64_t chunk_slot0[kMaxChunks + 1];            // X rows (in exchange order) of chunk k: [slot0[k], slot0[k+1])
+    int64_t close_lo[kMaxChunks], close_n[kMaxChunks];   // our result rows completed by chunk k (relative to p_lo)
+    int64_t ct_row[1024];                           // global row of Ct in X slot i
+    int nops;
+    PlanOp ops[2 * kMaxChunks * 1024 / 1 > 65536 ? 65536 : 2 * kMaxChunks * 1024];
+};
+
+// rows of chunk k that belong to peer g: [rows_lo(g, k), rows_lo(g, k + 1))
+inline int64_t rows_lo(int64_t M, int G, int nchunks, int g, int k) {
+    const int64_t n = part_lo(M, G, g + 1) - part_lo(M, G, g);
+    return part_lo(M, G, g) + part_lo(n, nchunks, k);
+}
+
+int build_plan(Plan& pl, int64_t L, int64_t M, int G, int me, int nchunks) {
+    const int64_t MM = M * M;
+    pl.b_lo = part_lo(L, G, me); pl.bl = part_lo(L, G, me + 1) - pl.b_lo;
+    pl.p_lo = part_lo(M, G, me); pl.pc = part_lo(M, G, me + 1) - pl.p_lo;
+    pl.row_x = pl.bl * MM; pl.row_r = L * MM;
+    pl.nops = 0;
+    int64_t slot = 0;
+    for (int k = 0; k < nchunks; ++k) {
+        pl.chunk_slot0[k] = slot;
+        pl.close_lo[k] = rows_lo(M, G, nchunks, me, k) - pl.p_lo;
+        pl.close_n[k] = rows_lo(M, G, nchunks, me, k + 1) - rows_lo(M, G, nchunks, me, k);
+        for (int g = 0; g < G; ++g) {
+            const int64_t lo = rows_lo(M, G, nchunks, g, k), n_send = rows_lo(M, G, nchunks, g, k + 1) - lo;
+            const int64_t gb_lo = part_lo(L, G, g), gbl = part_lo(L, G, g + 1) - gb_lo;    // b range of rank g
+            for (int64_t i = 0; i < n_send; ++i) pl.ct_row[slot + i] = lo + i;
+            if (g == me) {
+                if (n_send > 0 && pl.bl > 0) {
+                    if (pl.nops >= (int)(sizeof(pl.ops) / sizeof(pl.ops[0]))) return QS_ERR_BAD_EXTENT;
+                    pl.ops[pl.nops++] = PlanOp{k, g, 2, slot * pl.row_x, (pl.close_lo[k] * L + pl.b_lo) * MM, pl.row_x, n_send};
+                }
+            } else {
+                // what we computed for peer g goes out row by row; what peer g computed for us comes in row by row
+                for (int64_t i = 0; i < n_send && pl.bl > 0; ++i) {
+                    if (pl.nops >= (int)(sizeof(pl.ops) / sizeof(pl.ops[0]))) return QS_ERR_BAD_EXTENT;
+                    pl.ops[pl.nops++] = PlanOp{k, g, 0, (slot + i) * pl.row_x, 0, pl.row_x, 1};
+                }
+                for (int64_t i = 0; i < pl.close_n[k] && gbl > 0; ++i) {
+                    if (pl.nops >= (int)(sizeof(pl.ops) / sizeof(pl.ops[0]))) return QS_ERR_BAD_EXTENT;
+                    pl.ops[pl.nops++] = PlanOp{k, g, 1, 0, ((pl.close_lo[k] + i) * L + gb_lo) * MM, gbl * MM, 1};
+                }
+            }
+            slot += n_send;
+        }
+    }
+    pl.chunk_slot0[nchunks] = slot;
+    return QS_OK;
+}
+
+}  // namespace
+
+struct Comm {
+    nccl_comm_t nccl = nullptr;
+    int rank = 0, world = 1, device = 0;
+    hipStream_t stream = nullptr;              // the exchange runs here, beside the caller's stream
+    hipEvent_t x_ready[kMaxChunks], r_ready[kMaxChunks], idle, done;
+};
+
+}  // namespace qs
+
+using namespace qs;
+
+extern "C" {
+
+const char* qs_last_comm_error(void) { return g_comm_err; }
+
+int qs_comm_unique_id(void* id) {
+    if (!id) return QS_ERR_NULL_POINTER;
+    if (!rccl().ok) {
+        snprintf(g_comm_err, sizeof(g_comm_err), "librccl.so.1 could not be loaded: %s", dlerror());
+        return QS_ERR_COMM;
+    }
+    NcclUniqueId uid;
+    if (int rc = rccl_status(rccl().get_unique_id(&uid), "ncclGetUniqueId")) return rc;
+    memcpy(id, &uid, sizeof(uid));
+    return QS_OK;
+}
+
+int qs_comm_init(void** comm, int rank, int world, const void* unique_id) {
+    if (!comm || !unique_id) return QS_ERR_NULL_POINTER;
+    if (world < 1 || rank < 0 || rank >= world) return QS_ERR_BAD_EXTENT;
+    if (!rccl().ok) {
+        snprintf(g_comm_err, sizeof(g_comm_err), "librccl.so.1 could not be loaded");
+        return QS_ERR_COMM;
+    }
+    Comm* c = new Comm;
+    c->rank = rank;
+    c->world = world;
+    c->device = current_device();
+    NcclUniqueId uid;
+    memcpy(&uid, unique_id, sizeof(uid));
+    if (int rc = rccl_status(rccl().comm_init_rank(&c->nccl, world, uid, rank), "ncclCommInitRank")) {
+        delete c;
+        return rc;
+    }
+    hipError_t e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
+    for (int i = 0; i < kMaxChunks && e == hipSuccess; ++i) {
+        e = hipEventCreateWithFlags(&c->x_ready[i], hipEventDisableTiming);
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&c->r_ready[i], hipEventDisableTiming);
+    }
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&c->idle, hipEventDisableTiming);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&c->done, hipEventDisableTiming);
+    if (e != hipSuccess) {
+        rccl().comm_destroy(c->nccl);
+        delete c;
+        return hip_status(e, "qs_comm_init: stream / events");
+    }
+    *comm = c;
+    return QS_OK;
+}
+
+int qs_comm_destroy(void* comm) {
+    if (!comm) return QS_ERR_NULL_POINTER;
+    Comm* c = (Comm*)comm;
+    (void)hipStreamSynchronize(c->stream);
+    int rc = rccl_status(rccl().comm_destroy(c->nccl), "ncclCommDestroy");
+    for (int i = 0; i < kMaxChunks; ++i) {
+        (void)hipEventDestroy(c->x_ready[i]);
+        (void)hipEventDestroy(c->r_ready[i]);
+    }
+    (void)hipEventDestroy(c->idle);
+    (void)hipEventDestroy(c->done);
+    (void)hipStreamDestroy(c->stream);
+    delete c;
+    return rc;
+}
+
+/* Exchange plan of one rank as numbers (no GPU, no RCCL): tests replay it on the CPU.  table: nops rows of
+ * {chunk, peer, kind, x_off, r_off, count, rows}; header: {b_lo, bl, p_lo, pc, row_x, row_r, nchunks}; ct_rows: M;
+ * chunks: per chunk {slot0, rows, close_lo, close_n}.  Returns the number of operations or a negative error. */
+int qs_sharded_exchange_plan(int64_t L, int64_t M, int world, int rank, int nchunks, int64_t* header, int64_t* ct_rows,
+                             int64_t* chunks, int64_t* table, int64_t table_rows) {
+    if (L <= 0 || M <= 0 || M > 1024 || world < 1 || rank < 0 || rank >= world) return QS_ERR_BAD_EXTENT;
+    if (!header || !ct_rows || !chunks || !table) return QS_ERR_NULL_POINTER;
+    if (nchunks < 1) nchunks = 4;
+    if (nchunks > kMaxChunks) nchunks = kMaxChunks;
+    static thread_local Plan plan;
+    if (int rc = build_plan(plan, L, M, world, rank, nchunks)) return rc;
+    if (plan.nops > table_rows) return QS_ERR_WORKSPACE;
+    const int64_t h[7] = {plan.b_lo, plan.bl, plan.p_lo, plan.pc, plan.row_x, plan.row_r, nchunks};
+    memcpy(header, h, sizeof(h));
+    for (int64_t i = 0; i < M; ++i) ct_rows[i] = plan.ct_row[i];
+    for (int k = 0; k < nchunks; ++k) {
+        chunks[4 * k] = plan.chunk_slot0[k];
+        chunks[4 * k + 1] = plan.chunk_slot0[k + 1] - plan.chunk_slot0[k];
+        chunks[4 * k + 2] = plan.close_lo[k];
+        chunks[4 * k + 3] = plan.close_n[k];
+    }
+    for (int i = 0; i < plan.nops; ++i) {
+        const PlanOp& o = plan.ops[i];
+        const int64_t row[7] = {o.chunk, o.peer, o.kind, o.x_off, o.r_off, o.count, o.rows};
+        memcpy(table + 7 * i, row, sizeof(row));
+    }
+    return plan.nops;
+}
+
+int qs_comm_rank(void* comm) { return comm ? ((Comm*)comm)->rank : QS_ERR_NULL_POINTER; }
+int qs_comm_world(void* comm) { return comm ? ((Comm*)comm)->world : QS_ERR_NULL_POINTER; }
+
+// workspace: Ct rows in exchange order | C^T | T1 (reused as X) | T2 | R
+int64_t qs_transform_two_body_sharded_workspace(int dtype, int64_t L, int64_t M, int world, int rank) {
+    if (!dtype_ok(dtype)) return QS_ERR_BAD_DTYPE;
+    if (L <= 0 || M <= 0 || L > 4096 || M > 1024 || world < 1 || rank < 0 || rank >= world) return QS_ERR_BAD_EXTENT;
+    const int64_t bl = part_lo(L, world, rank + 1) - part_lo(L, world, rank);
+    const int64_t pc = part_lo(M, world, rank + 1) - part_lo(M, world, rank);
+    const int64_t t1 = L * bl * L * M, x = M * bl * M * M, t2 = L * bl * M * M, r = pc * L * M * M;
+    const int64_t elems = 2 * ((L * M + 1) & ~int64_t(1)) + (t1 > x ? t1 : x) + t2 + r + 8;
+    return elems * (int64_t)elem_size(dtype);
+}
+
+int qs_transform_two_body_sharded(void* comm, int dtype, const void* u_bslab, const void* C, const void* Ct,
+                                  void* out_pslab, void* work, int64_t work_bytes, int64_t L, int64_t M, int nchunks,
+                                  void* stream) {
+    dispatch_reset();
+    if (!comm) return QS_ERR_NULL_POINTER;
+    Comm* c = (Comm*)comm;
+    const int G = c->world, me = c->rank;
+    if (!dtype_ok(dtype)) return QS_ERR_BAD_DTYPE;
+    if (L <= 0 || M <= 0 || L > 4096 || M > 1024) return QS_ERR_BAD_EXTENT;
+    if (!C || !Ct || !work) return QS_ERR_NULL_POINTER;
+    const size_t es = elem_size(dtype);
+    const int64_t b_lo = part_lo(L, G, me), bl = part_lo(L, G, me + 1) - b_lo;
+    const int64_t p_lo = part_lo(M, G, me), pc = part_lo(M, G, me + 1) - p_lo;
+    if ((bl > 0 && !u_bslab) || (pc > 0 && !out_pslab)) return QS_ERR_NULL_POINTER;
+    if (!aligned(C, es) || !aligned(Ct, es) || !aligned(work, 16) || (u_bslab && !aligned(u_bslab, es)) ||
+        (out_pslab && !aligned(out_pslab, es)))
+        return QS_ERR_MISALIGNED;
+    if (out_pslab && (out_pslab == u_bslab || out_pslab == work)) return QS_ERR_ALIAS;
+    if (work_bytes < qs_transform_two_body_sharded_workspace(dtype, L, M, G, me)) return QS_ERR_WORKSPACE;
+    if (current_device() != c->device) return QS_ERR_BAD_EXTENT;      // the communicator belongs to another device
+    if (nchunks < 1) nchunks = 4;
+    if (nchunks > kMaxChunks) nchunks = kMaxChunks;
+    hipStream_t s = (hipStream_t)stream;
+    const int64_t MM = M * M, width = dtype == QS_C128 ? 2 : 1;
+
+    auto at = [&](void* base, int64_t elems) { return (void*)((char*)base + (size_t)elems * es); };
+    const int64_t lm = (L * M + 1) & ~int64_t(1);
+    void* CtX = work;                      // rows of Ct in exchange order (chunk-major, then peer)
+    void* CT = at(CtX, lm);
+    void* T1 = at(CT, lm);                 // (L*bl*L, M); later X (M rows in exchange order) x (bl*M*M)
+    const int64_t t1 = L * bl * L * M, xs = M * bl * MM;
+    void* T2 = at(T1, t1 > xs ? t1 : xs);  // (L*bl, M, M)
+    void* R = at(T2, L * bl * MM);         // (pc, L, M*M): row p_loc, columns b of every sender
+    void* X = T1;
+
+    static thread_local Plan plan;       // (large: not on the stack)
+    if (M > 1024) return QS_ERR_BAD_EXTENT;
+    if (int prc = build_plan(plan, L, M, G, me, nchunks)) return prc;
+    // ---- Ct rows in exchange order (device-to-device row copies on the caller's stream: runs of consecutive rows)
+    for (int64_t i = 0; i < M;) {
+        int64_t n = 1;
+        while (i + n < M && plan.ct_row[i + n] == plan.ct_row[i] + n) ++n;
+        hipError_t ce = hipMemcpyAsync(at(CtX, i * L), (const char*)Ct + (size_t)(plan.ct_row[i] * L) * es,
+                                       (size_t)(n * L) * es, hipMemcpyDeviceToDevice, s);
+        if (ce != hipSuccess) return hip_status(ce, "qs_transform_two_body_sharded: Ct rows");
+        i += n;
+    }
+    int rc = QS_OK;
+    if (bl > 0) {
+        rc = transpose_small(dtype, C, CT, L, M, s);
+        if (rc) return rc;
+        // d:  T1[(a,b,c), s] = u[(a,b,c), d] C[d, s]
+        rc = qs_matmul(dtype, u_bslab, C, T1, L * bl * L, M, L, L, M, M, 1, 0, 0, 0, 0, s);
+        if (rc) return rc;
+        // c:  T2[(a,b)][r, s] = CT[r, c] T1[(a,b)][c, s]
+        rc = qs_matmul(dtype, CT, T1, T2, M, M, L, L, M, M, L * bl, 0, L * M, MM, 0, s);
+        if (rc) return rc;
+    }
+    // the exchange must not start before earlier work on the caller's stream that R / X might still be read by
+    hipError_t e = hipEventRecord(c->idle, s);
+    if (e == hipSuccess) e = hipStreamWaitEvent(c->stream, c->idle, 0);
+    if (e != hipSuccess) return hip_status(e, "qs_transform_two_body_sharded: stream order");
+
+    const int64_t row_x = plan.row_x;
+    auto close_chunk = [&](int k) -> int {
+        // out[p][q, (r,s)] = Ct[q, :] . R[p][:, (r,s)] for our rows of chunk k, once they are complete
+        const int64_t lo = plan.close_lo[k], n = plan.close_n[k];
+        if (n <= 0) return QS_OK;
+        hipError_t ee = hipStreamWaitEvent(s, c->r_ready[k], 0);
+        if (ee != hipSuccess) return hip_status(ee, "qs_transform_two_body_sharded: wait for rows");
+        return qs_matmul(dtype, Ct, at(R, lo * L * MM), at(out_pslab, lo * M * MM), M, MM, L, L, MM, MM, n, 0, L * MM,
+                         M * MM, 0, s);
+    };
+    int op = 0;
+    for (int k = 0; k < nchunks; ++k) {
+        const int64_t slot0 = plan.chunk_slot0[k], rows_k = plan.chunk_slot0[k + 1] - slot0;
+        // a:  X[slot, (b,r,s)] = CtX[slot, a] T2[a, (b,r,s)]   for the rows of chunk k
+        if (bl > 0 && rows_k > 0) {
+            rc = qs_matmul(dtype, at(CtX, slot0 * L), T2, at(X, slot0 * row_x), rows_k, row_x, L, L, row_x, row_x, 1, 0, 0,
+                           0, 0, s);
+            if (rc) return rc;
+        }
+        e = hipEventRecord(c->x_ready[k], s);
+        if (e == hipSuccess) e = hipStreamWaitEvent(c->stream, c->x_ready[k], 0);
+        if (e != hipSuccess) return hip_status(e, "qs_transform_two_body_sharded: chunk ready");
+        // exchange of chunk k on the communicator's stream: one message per row and peer, all peers in one group
+        if (int grc = rccl_status(rccl().group_start(), "ncclGroupStart")) return grc;
+        for (; op < plan.nops && plan.ops[op].chunk == k; ++op) {
+            const PlanOp& o = plan.ops[op];
+            int orc = QS_OK;
+            if (o.kind == 2) {
+                // our own rows: straight into R (strided copy: a row of X is bl*MM long, a row of R is L*MM long)
+                hipError_t me_e = hipMemcpy2DAsync(at(R, o.r_off), (size_t)plan.row_r * es, at(X, o.x_off), (size_t)row_x * es,
+                                                   (size_t)o.count * es, (size_t)o.rows, hipMemcpyDeviceToDevice, c->stream);
+                if (me_e != hipSuccess) orc = hip_status(me_e, "own rows");
+            } else if (o.kind == 0) {
+                orc = rccl_status(rccl().send(at(X, o.x_off), (size_t)(o.count * width), kNcclFloat64, o.peer, c->nccl,
+                                              c->stream), "ncclSend");
+            } else {
+                orc = rccl_status(rccl().recv(at(R, o.r_off), (size_t)(o.count * width), kNcclFloat64, o.peer, c->nccl,
+                                              c->stream), "ncclRecv");
+            }
+            if (orc) { rccl().group_end(); return orc; }
+        }
+        if (int grc = rccl_status(rccl().group_end(), "ncclGroupEnd")) return grc;
+        e = hipEventRecord(c->r_ready[k], c->stream);
+        if (e != hipSuccess) return hip_status(e, "qs_transform_two_body_sharded: rows ready");
+        // while chunk k travels: close chunk k - 1 (its rows have arrived or are about to)
+        if (k > 0) { rc = close_chunk(k - 1); if (rc) return rc; }
+    }
+    rc = close_chunk(nchunks - 1);
+    if (rc) return rc;
+    // the caller's stream ends behind everything the exchange stream did (workspace and R are free after `stream`)
+    e = hipEventRecord(c->done, c->stream);
+    if (e == hipSuccess) e = hipStreamWaitEvent(s, c->done, 0);
+    if (e != hipSuccess) return hip_status(e, "qs_transform_two_body_sharded: join");
+    note_dispatch("rccl grouped send/recv x%d chunks", nchunks);
+    return QS_OK;
+}
+
+}  // extern "C"

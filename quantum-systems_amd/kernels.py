@@ -511,6 +511,76 @@ def antisymmetrize_(u):
     return antisymmetrize(u, out=u)
 
 
+class RcclComm:
+    """The C ABI's communicator (``qs_comm_init``: RCCL over xGMI, one process per GPU) for hosts that drive the
+    library from Python without ``torch.distributed``.  ``unique_id()`` on one rank, the 128 bytes to the others by
+    any means, then ``RcclComm(rank, world, id_bytes)`` on every rank (collective)."""
+
+    @staticmethod
+    def unique_id():
+        import ctypes
+
+        buf = (ctypes.c_char * 128)()
+        check(_lib.load().qs_comm_unique_id(ctypes.cast(buf, ctypes.c_void_p)), "qs_comm_unique_id")
+        return bytes(buf)
+
+    def __init__(self, rank, world, unique_id):
+        import ctypes
+
+        if len(unique_id) != 128:
+            raise ValueError("the unique id is 128 bytes")
+        self._handle = ctypes.c_void_p()
+        buf = ctypes.create_string_buffer(bytes(unique_id), 128)
+        check(_lib.load().qs_comm_init(ctypes.byref(self._handle), int(rank), int(world),
+                                       ctypes.cast(buf, ctypes.c_void_p)), "qs_comm_init")
+        self.rank, self.world = int(rank), int(world)
+
+    def close(self):
+        if self._handle:
+            check(_lib.load().qs_comm_destroy(self._handle), "qs_comm_destroy")
+            self._handle = None
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+        return False
+
+    def transform_two_body(self, u_bslab, C, C_tilde=None, out=None, nchunks=4):
+        """``out[p_lo:p_hi]`` of the transform from ``u[:, b_lo:b_hi]`` (balanced splits): the whole sharded
+        transform in ONE C-ABI call -- local contractions, chunked grouped send / receive on the communicator's
+        stream overlapped with them, closing contraction (``qs_transform_two_body_sharded``)."""
+        lib = _lib.load()
+        if C_tilde is None:
+            C_tilde = default_bra(C)
+        dt = result_dtype(u_bslab, C, C_tilde)
+        u_bslab, C, Ct = _dev(u_bslab, dt), _dev(C, dt), _dev(C_tilde, dt)
+        L, M = C.shape
+        code = dtype_code(dt)
+        base, extra = divmod(M, self.world)
+        pc = base + (1 if self.rank < extra else 0)
+        base, extra = divmod(L, self.world)
+        bl = base + (1 if self.rank < extra else 0)
+        if tuple(u_bslab.shape) != (L, bl, L, L) or tuple(Ct.shape) != (M, L):
+            raise ValueError(f"rank {self.rank}: expected a slab of shape {(L, bl, L, L)} and C_tilde {(M, L)}")
+        if out is None:
+            out = torch.empty((pc, M, M, M), dtype=dt, device=u_bslab.device)
+        else:
+            _check_out(out, (pc, M, M, M), dt, "RcclComm.transform_two_body")
+        nbytes = check(lib.qs_transform_two_body_sharded_workspace(code, L, M, self.world, self.rank), "workspace query")
+        with _on_device_of(u_bslab, C, Ct, out):
+            work = workspace.get(nbytes, u_bslab.device)
+            _ran(
+                lib.qs_transform_two_body_sharded(
+                    self._handle, code, u_bslab.data_ptr(), C.data_ptr(), Ct.data_ptr(), out.data_ptr(),
+                    work.data_ptr(), work.numel(), L, M, int(nchunks), _stream(),
+                ),
+                "qs_transform_two_body_sharded",
+            )
+        return out
+
+
 def tuning_set(key, value):
     """Tuning / test hook: kernel-choice override for the CALLING THREAD only
     (the library keeps no process-global mutable state)."""
