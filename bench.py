@@ -22,7 +22,10 @@ over its leading index p.  Layouts:
   sharded     u sharded over its second index, one all-to-all, out of place;
   inplace     the same exchange inside the output buffer: input slab + output
               slab + O(l^3) per GPU -- the form BASELINE.json configs[4]
-              (l=512 complex128, 1.1 TB) needs; slabs are generated per rank.
+              (l=512 complex128, 1.1 TB) needs; slabs are generated per rank;
+  rccl        the sharded layout in ONE C-ABI call per step (qs_transform_two_body_sharded:
+              RCCL driven directly, grouped send/recv per peer, chunked exchange on its own
+              stream overlapped with the products).
 The north star's single all-gather (replicating the p-sharded result) is timed
 as a second leg and reported next to the no-collective value; `--gather` makes
 it part of `value`.
@@ -54,7 +57,7 @@ def parse(argv=None):
     ap.add_argument("--orbitals", "-l", dest="l", type=int, default=256,
                     help="number of orbitals l (named so that torch.distributed.run does not read it as --l*)")
     ap.add_argument("--dtype", choices=["f64", "c128"], default="f64")
-    ap.add_argument("--layout", choices=["auto", "replicated", "sharded", "inplace"], default="auto")
+    ap.add_argument("--layout", choices=["auto", "replicated", "sharded", "inplace", "rccl"], default="auto")
     ap.add_argument("--gather", action="store_true", help="make the all-gather of the result part of `value`")
     ap.add_argument("--no-gather-leg", action="store_true", help="skip the second, gather-inclusive timing leg at N > 1")
     ap.add_argument("--fresh-c", choices=["auto", "on", "off"], default="auto",
@@ -571,6 +574,18 @@ def run_rank(args):
             C, Ct = coeff(i)
             return sharded.transform_two_body_sharded(u, C, Ct, rank, world)
         layout = "u b-sharded, one all-to-all, out p-sharded (out of place)"
+    elif layout_kind == "rccl":
+        ids = [kernels.RcclComm.unique_id() if rank == 0 else None]
+        if use_dist:
+            dist.broadcast_object_list(ids, src=0)         # 128 bytes, by the job's existing rendezvous
+        with _StdoutToStderr():
+            rccl_comm = kernels.RcclComm(rank, world, ids[0])
+        out_slab = torch.empty((p_hi - p_lo, l, l, l), dtype=dtype, device=device)
+
+        def local_step(i):
+            C, Ct = coeff(i)
+            return rccl_comm.transform_two_body(u, C, Ct, out=out_slab)
+        layout = "u b-sharded, one C-ABI call: RCCL grouped send/recv, chunked exchange overlapped with the products"
     else:
         keep = torch.empty((l // world + 1, l, l, l), dtype=dtype, device=device)
 
@@ -591,7 +606,7 @@ def run_rank(args):
     # second leg at N > 1: the same steps followed by the north star's all-gather of the result
     gather_leg = None
     if world > 1 and not with_gather and not args.no_gather_leg and l**4 * es * (2 + 4 / world) < 0.85 * HBM_BYTES \
-            and layout_kind in ("replicated", "sharded"):
+            and layout_kind in ("replicated", "sharded", "rccl"):
         k2 = max(1, min(args.steps, 3))
         e2, _, ps2, _ = timed_steps(torch, lambda i: gather(local_step(i)), k2, 1, barrier)
         gather_leg = (e2, k2, ps2)

@@ -98,6 +98,20 @@ int qs_transform_two_body(int dtype, const void* u, const void* C,
                           void* stream);
 
 /*
+ * The same transform IN PLACE, for a caller that drops the old tensor anyway
+ * (BasisSet.change_basis rebinds self.u, basis_set.py:374-377): `u` (L,L,L,L) is
+ * overwritten and the result (M,M,M,M), M <= L, is left at the START of its
+ * storage.  Peak memory is the tensor plus ONE L^3 M spare buffer instead of
+ * tensor + workspace + result: the four contractions ping-pong between the two.
+ * Same arithmetic, same order; l = 256 fp64 needs 69 GB instead of 103 GB, and
+ * the largest fp64 basis one MI355X holds grows from 320 to ~360 orbitals.
+ */
+int64_t qs_transform_two_body_inplace_workspace(int dtype, int64_t L, int64_t M);
+int qs_transform_two_body_inplace(int dtype, void* u, const void* C,
+                                  const void* Ct, void* work, int64_t work_bytes,
+                                  int64_t L, int64_t M, void* stream);
+
+/*
  * Same transform restricted to rows [a_lo, a_hi) of the leading index of `u`
  * for the contractions over d, c, b only:
  *   v[a,q,r,s] = sum_bcd Ct[q,b] u[a,b,c,d] C[c,r] C[d,s],  a in [a_lo,a_hi)

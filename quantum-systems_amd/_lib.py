@@ -29,6 +29,9 @@ SIGNATURES = {
     "qs_transform_two_body_workspace": (c_i64, [c_int, c_i64, c_i64]),
     "qs_transform_two_body": (
         c_int, [c_int, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_i64, c_i64, c_i64, c_ptr]),
+    "qs_transform_two_body_inplace_workspace": (c_i64, [c_int, c_i64, c_i64]),
+    "qs_transform_two_body_inplace": (
+        c_int, [c_int, c_ptr, c_ptr, c_ptr, c_ptr, c_i64, c_i64, c_i64, c_ptr]),
     "qs_transform_two_body_partial_workspace": (c_i64, [c_int, c_i64, c_i64, c_i64]),
     "qs_transform_two_body_partial": (
         c_int, [c_int, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_i64, c_i64, c_i64, c_i64, c_ptr]),

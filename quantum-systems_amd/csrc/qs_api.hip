@@ -279,6 +279,39 @@ int qs_transform_two_body(int dtype, const void* u, const void* C, const void* C
     return gemm(dtype, Ct, WA, out, M, M * M * M, L, L, M * M * M, M * M * M, 1, 0, 0, 0, s);
 }
 
+int64_t qs_transform_two_body_inplace_workspace(int dtype, int64_t L, int64_t M) {
+    if (!dtype_ok(dtype)) return QS_ERR_BAD_DTYPE;
+    if (!extents_ok(L, M) || M > L) return QS_ERR_BAD_EXTENT;
+    return (even_up(L * M) + L * L * L * M) * (int64_t)elem_size(dtype);
+}
+
+int qs_transform_two_body_inplace(int dtype, void* u, const void* C, const void* Ct, void* work,
+                                  int64_t work_bytes, int64_t L, int64_t M, void* stream) {
+    dispatch_reset();
+    if (!dtype_ok(dtype)) return QS_ERR_BAD_DTYPE;
+    if (!extents_ok(L, M) || M > L) return QS_ERR_BAD_EXTENT;
+    if (!u || !C || !Ct || !work) return QS_ERR_NULL_POINTER;
+    const size_t es = elem_size(dtype);
+    if (!aligned(u, es) || !aligned(C, es) || !aligned(Ct, es) || !aligned(work, 16)) return QS_ERR_MISALIGNED;
+    if (work == u) return QS_ERR_ALIAS;
+    if (work_bytes < qs_transform_two_body_inplace_workspace(dtype, L, M)) return QS_ERR_WORKSPACE;
+    hipStream_t s = (hipStream_t)stream;
+    void* CT = work;
+    void* B = at(work, even_up(L * M), es);
+    // the four contractions ping-pong between the tensor's own storage (A) and ONE spare buffer (B): every
+    // product reads one and writes the other, and each intermediate fits where it goes (M <= L):
+    //   d: A (L^4) -> B (L^3 M)   c: B -> A (L^2 M^2)   b: A -> B (L M^3)   a: B -> A (M^4)
+    int rc = transpose_small(dtype, C, CT, L, M, s);
+    if (rc) return rc;
+    rc = gemm(dtype, u, C, B, L * L * L, M, L, L, M, M, 1, 0, 0, 0, s);
+    if (rc) return rc;
+    rc = gemm(dtype, CT, B, u, M, M, L, L, M, M, L * L, 0, L * M, M * M, s);
+    if (rc) return rc;
+    rc = gemm(dtype, Ct, u, B, M, M * M, L, L, M * M, M * M, L, 0, L * M * M, M * M * M, s);
+    if (rc) return rc;
+    return gemm(dtype, Ct, B, u, M, M * M * M, L, L, M * M * M, M * M * M, 1, 0, 0, 0, s);
+}
+
 int64_t qs_transform_two_body_partial_workspace(int dtype, int64_t L, int64_t M, int64_t rows) {
     if (!dtype_ok(dtype)) return QS_ERR_BAD_DTYPE;
     if (!extents_ok(L, M) || rows <= 0 || rows > L) return QS_ERR_BAD_EXTENT;

@@ -217,6 +217,32 @@ def transform_two_body(u, C, C_tilde=None, out=None):
     return out
 
 
+def transform_two_body_(u, C, C_tilde=None):
+    """The transform IN PLACE: ``u`` (L,L,L,L; float64 / complex128, contiguous, owning its storage) is overwritten
+    and the result (M,M,M,M), M <= L, is returned as a view of the start of its storage.  One L^3 M spare buffer
+    instead of workspace + result (qs_transform_two_body_inplace): for callers that drop the old tensor."""
+    lib = _lib.load()
+    if C_tilde is None:
+        C_tilde = default_bra(C)
+    dt = result_dtype(u, C, C_tilde)
+    if not isinstance(u, torch.Tensor) or not u.is_cuda or u.dtype != dt or not u.is_contiguous():
+        raise ValueError("the in-place transform needs a contiguous device tensor that already has the result dtype")
+    C, Ct = _dev(C, dt), _dev(C_tilde, dt)
+    L, M = C.shape
+    if tuple(u.shape) != (L, L, L, L) or tuple(Ct.shape) != (M, L) or M > L:
+        raise ValueError(f"u {tuple(u.shape)}, C {tuple(C.shape)}, C_tilde {tuple(Ct.shape)}: need u (L,L,L,L) and M <= L")
+    code = dtype_code(dt)
+    nbytes = check(lib.qs_transform_two_body_inplace_workspace(code, L, M), "workspace query")
+    with _on_device_of(u, C, Ct):
+        work = workspace.get(nbytes, u.device)
+        _ran(
+            lib.qs_transform_two_body_inplace(code, u.data_ptr(), C.data_ptr(), Ct.data_ptr(), work.data_ptr(),
+                                              work.numel(), L, M, _stream()),
+            "qs_transform_two_body_inplace",
+        )
+    return u.reshape(-1)[: M**4].reshape(M, M, M, M)
+
+
 class TransformPlan:
     """The four-index transform of a RESIDENT ``u`` captured once as a HIP graph,
     for loops that transform every step with new coefficients (the

@@ -347,3 +347,74 @@ def test_double_doubling_warns_on_device():
         warnings.simplefilter("always")
         assert gos._basis_set.change_to_general_orbital_basis() is None
     assert len(w) == 1 and gos.l == 8
+
+
+def test_change_basis_reuses_the_storage_of_the_tensor_it_drops():
+    # the reference rebinds self.u and lets the old array go (basis_set.py:374-377); on the device the old
+    # storage becomes the result's storage (in-place transform, one spare buffer) -- unless anybody else can
+    # still see the old array, in which case it stays intact exactly as in NumPy
+    import quantum_systems_amd as qsa
+    from quantum_systems_amd import kernels as K
+
+    l = 24
+    rng = np.random.default_rng(8)
+    u = rng.standard_normal((l,) * 4)
+    h = rng.standard_normal((l, l))
+    C = np.linalg.qr(rng.standard_normal((l, l)))[0]
+    ref = orc.transform_two_body(u, C)
+
+    def system():
+        bs = qsa.BasisSet(l, 1, np=hip)
+        bs.h, bs.s, bs.u = hip.asarray(h), hip.asarray(np.eye(l)), hip.asarray(u)
+        bs.donate_u_from = 8                                   # (default: from 96 orbitals up)
+        return bs
+
+    bs = system()
+    ptr = torch.as_tensor(bs.u).data_ptr()
+    bs.change_basis(hip.asarray(C))
+    assert K.last_dispatch() != "" and torch.as_tensor(bs.u).data_ptr() == ptr          # same storage
+    np.testing.assert_allclose(H(bs.u), ref, rtol=1e-11, atol=1e-12)
+    # a second reference to the old array: no reuse, the old array survives unchanged
+    bs = system()
+    keep = bs.u
+    bs.change_basis(hip.asarray(C))
+    assert torch.as_tensor(bs.u).data_ptr() != keep.data_ptr()
+    assert np.array_equal(H(keep), u)
+    np.testing.assert_allclose(H(bs.u), ref, rtol=1e-11, atol=1e-12)
+    # a view of the old array counts as well
+    bs = system()
+    view = bs.u[0]
+    bs.change_basis(hip.asarray(C))
+    assert np.array_equal(H(view), u[0])
+    # shrinking basis: result at the start of the old storage; growing basis / complex C on a real u: ordinary path
+    bs = system()
+    ptr = torch.as_tensor(bs.u).data_ptr()
+    bs.change_basis(hip.asarray(C[:, :17].copy()))
+    assert bs.l == 17 and torch.as_tensor(bs.u).data_ptr() == ptr
+    np.testing.assert_allclose(H(bs.u), orc.transform_two_body(u, C[:, :17]), rtol=1e-11, atol=1e-12)
+    bs = system()
+    Cc = C.astype(np.complex128) * np.exp(0.3j)
+    bs.change_basis(hip.asarray(Cc))
+    np.testing.assert_allclose(H(bs.u), orc.transform_two_body(u, Cc), rtol=1e-11, atol=1e-12)
+
+
+def test_inplace_transform_kernel_wrapper():
+    from quantum_systems_amd import kernels as K
+
+    rng = np.random.default_rng(81)
+    for (L, M, cplx) in ((20, 20, False), (130, 128, False), (18, 11, True)):
+        u = rng.standard_normal((L,) * 4)
+        C = rng.standard_normal((L, M)) / np.sqrt(L)
+        Ct = rng.standard_normal((M, L)) / np.sqrt(L)
+        if cplx:
+            u = u + 1j * rng.standard_normal((L,) * 4)
+            C = C + 1j * rng.standard_normal((L, M))
+            Ct = Ct + 1j * rng.standard_normal((M, L))
+        du = torch.from_numpy(u).cuda()
+        ref = K.transform_two_body(du, torch.from_numpy(C).cuda(), torch.from_numpy(Ct).cuda())
+        got = K.transform_two_body_(du, torch.from_numpy(C).cuda(), torch.from_numpy(Ct).cuda())
+        assert got.data_ptr() == du.data_ptr() and tuple(got.shape) == (M,) * 4
+        assert torch.equal(got, ref)                           # same products in the same order: bit-identical
+    with pytest.raises(ValueError):
+        K.transform_two_body_(torch.zeros((4,) * 4, dtype=torch.float64, device="cuda"),
+                              torch.zeros((4, 6), dtype=torch.float64, device="cuda"))      # growing basis

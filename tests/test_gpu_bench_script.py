@@ -126,6 +126,19 @@ def test_self_launch_bandwidth_workload_two_ranks():
     assert d["roofline"]["kernel"] == "qs::spin_expand_kernel<double, f64x2>"
 
 
+def test_rccl_layout_with_a_one_rank_group():
+    # --layout rccl: the whole sharded step is one C-ABI call on a real RCCL communicator (one rank here; the
+    # driver's node gives it one GPU per rank)
+    env = dict(os.environ, QS_BENCH_FORCE_DIST="1", MASTER_ADDR="127.0.0.1", MASTER_PORT="29691",
+               RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "3", "--warmup", "1",
+           "--orbitals", "64", "--layout", "rccl", "--no-cpu-baseline", "--no-probes"]
+    res = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=ROOT, env=env)
+    assert res.returncode == 0, res.stderr[-3000:]
+    d = json.loads([ln for ln in res.stdout.splitlines() if ln.strip().startswith("{")][0])
+    assert "RCCL" in d["config"]["layout"] and d["parity"]["ok"] is True and d["n_ranks_seen"] == 1
+
+
 def test_failed_parity_exits_nonzero(monkeypatch):
     # the parity bound is enforced, not just printed: an impossible bound makes the run fail
     import importlib.util

@@ -625,3 +625,21 @@ def test_replicated_layout_matches_full_transform(K):
             lo, hi = sharded.SlabPartition(l, world).bounds(rank)
             slab = sharded.transform_two_body_replicated(u, C, Ct, rank, world)
             assert (slab - full[lo:hi]).abs().max().item() <= 1e-12 * full.abs().max().item()
+
+
+def test_spin_squared_two_body_with_1024_spin_orbitals(K):
+    # n = 1024 (l = 512 spatial orbitals, BASELINE.json configs[4]): the rows of S_x, S_y, S_z staged per workgroup
+    # need 96 KB of LDS -- the kernel opts in beyond 64 KB (per device) instead of refusing n > 682
+    n = 1024
+    g = torch.Generator(device="cuda:0").manual_seed(1024)
+    S = torch.complex(torch.randn(3, n, n, dtype=torch.float64, device="cuda:0", generator=g),
+                      torch.randn(3, n, n, dtype=torch.float64, device="cuda:0", generator=g))
+    for anti in (False, True):
+        rows = K.spin_squared_two_body(S, antisymmetrize=anti, p_lo=700, p_hi=701)       # one row: 17 GB
+        assert K.last_dispatch() == "qs::spin2_tb_kernel" and tuple(rows.shape) == (1, n, n, n)
+        for q in (0, 513, 1023):
+            ref = sum(torch.outer(S[k, 700], S[k, q]) for k in range(3))                  # [r, s] = S[p,r] S[q,s]
+            if anti:
+                ref = ref - sum(torch.outer(S[k, q], S[k, 700]) for k in range(3)).t()    # - S[p,s] S[q,r]
+            assert (rows[0, q] - ref).abs().max().item() <= 1e-12 * ref.abs().max().item()
+        del rows
