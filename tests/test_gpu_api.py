@@ -12,6 +12,7 @@ import pytest
 import torch
 
 import quantum_systems_amd as qsa
+from oracle import qs_oracle as orc
 from quantum_systems_amd import (
     BasisSet, GeneralOrbitalSystem, RandomBasisSet, SpatialOrbitalSystem,
     construct_custom_system, hip, setup_basis_set,
