@@ -57,6 +57,23 @@ def _deliver(t, np):
     return np.asarray(to_host(t))
 
 
+def _sole_owner(t):
+    """True when nothing but ``t`` itself can reach its storage: no view, no alias, no Python reference to the
+    tensor it aliases.  (A device array made by ``wrap`` is an alias of the tensor it was made from -- ``t._base``
+    -- and views of it attach to that base.)"""
+    if t.storage_offset() != 0 or t.untyped_storage().nbytes() != t.numel() * t.element_size():
+        return False
+    if t._use_count() != 1:
+        return False
+    base = t._base
+    if base is None:
+        return True
+    # nobody else holds the base: its Python object is referenced by this variable, getrefcount's argument and
+    # the tensor implementation's own slot (3; a user's variable makes it 4), the implementation by that object
+    # and by t's base link (2; every view adds one)
+    return sys.getrefcount(base) == 3 and base._use_count() == 2 and base._base is None
+
+
 def _module_of(np):
     return numpy if np is None else np
 
@@ -320,10 +337,11 @@ class BasisSet:
             donate = (
                 type(self).transform_two_body_elements is BasisSet.transform_two_body_elements
                 and is_device_module(np) and isinstance(old, torch.Tensor) and old.is_cuda
-                and len(old.shape) == 4 and old.is_contiguous() and old._base is None
+                and len(old.shape) == 4 and old.is_contiguous()
                 and C.shape[1] <= C.shape[0] and C.shape[0] >= self.donate_u_from
                 and old.dtype == kernels.result_dtype(old, d_C, d_Ct)
-                and old._use_count() == 1 and sys.getrefcount(old) <= 3       # attribute + `old` + the call's argument
+                and sys.getrefcount(old) <= 3                     # the attribute, `old`, the call's argument
+                and _sole_owner(old)
             )
             if donate:
                 setattr(self, slot, None)
