@@ -358,14 +358,16 @@ def dominant_kernel(log):
         for item in rec.split(";"):
             if not item:
                 continue
-            name, _, rep = item.partition(" x")
+            name, _, rep = item.rpartition(" x")
+            if not name or not rep.isdigit():
+                name, rep = item, ""
             k = int(rep) if rep else 1
             if name not in counts:
                 order.append(name)
             counts[name] = counts.get(name, 0) + k
     if not counts:
         return "unknown", 1, ""
-    heavy = [n for n in order if "transpose" not in n] or order
+    heavy = [n for n in order if "transpose" not in n and not n.startswith("rccl")] or order
     total = sum(counts[n] for n in heavy)
     text = "; ".join(f"{n} x{counts[n]}" for n in order)
     return max(heavy, key=lambda n: counts[n]), total, text

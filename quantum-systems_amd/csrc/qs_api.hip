@@ -206,14 +206,27 @@ int qs_matmul(int dtype, const void* A, const void* B, void* out, int64_t m, int
               int64_t lda, int64_t ldb, int64_t ldc, int64_t batch, int64_t stride_a,
               int64_t stride_b, int64_t stride_c, int accumulate, void* stream) {
     dispatch_reset();
+    return matmul_checked(dtype, A, B, out, m, n, k, lda, ldb, ldc, batch, stride_a, stride_b, stride_c, accumulate,
+                          (hipStream_t)stream);
+}
+
+}  // extern "C"
+
+namespace qs {
+// qs_matmul without the reset of the dispatch record (entry points that issue several products: qs_comm.hip)
+int matmul_checked(int dtype, const void* A, const void* B, void* out, int64_t m, int64_t n, int64_t k, int64_t lda,
+                   int64_t ldb, int64_t ldc, int64_t batch, int64_t stride_a, int64_t stride_b, int64_t stride_c,
+                   int accumulate, hipStream_t stream) {
     if (!dtype_ok(dtype)) return QS_ERR_BAD_DTYPE;
     if (!A || !B || !out) return QS_ERR_NULL_POINTER;
     const size_t es = elem_size(dtype);
     if (!aligned(A, es) || !aligned(B, es) || !aligned(out, es)) return QS_ERR_MISALIGNED;
     if (stride_a < 0 || stride_b < 0 || stride_c < 0) return QS_ERR_BAD_EXTENT;
-    return gemm(dtype, A, B, out, m, n, k, lda, ldb, ldc, batch, stride_a, stride_b, stride_c,
-                (hipStream_t)stream, accumulate);
+    return gemm(dtype, A, B, out, m, n, k, lda, ldb, ldc, batch, stride_a, stride_b, stride_c, stream, accumulate);
 }
+}  // namespace qs
+
+extern "C" {
 
 int64_t qs_transform_two_body_workspace(int dtype, int64_t L, int64_t M) {
     if (!dtype_ok(dtype)) return QS_ERR_BAD_DTYPE;

@@ -332,10 +332,10 @@ int qs_transform_two_body_sharded(void* comm, int dtype, const void* u_bslab, co
         rc = transpose_small(dtype, C, CT, L, M, s);
         if (rc) return rc;
         // d:  T1[(a,b,c), s] = u[(a,b,c), d] C[d, s]
-        rc = qs_matmul(dtype, u_bslab, C, T1, L * bl * L, M, L, L, M, M, 1, 0, 0, 0, 0, s);
+        rc = matmul_checked(dtype, u_bslab, C, T1, L * bl * L, M, L, L, M, M, 1, 0, 0, 0, 0, s);
         if (rc) return rc;
         // c:  T2[(a,b)][r, s] = CT[r, c] T1[(a,b)][c, s]
-        rc = qs_matmul(dtype, CT, T1, T2, M, M, L, L, M, M, L * bl, 0, L * M, MM, 0, s);
+        rc = matmul_checked(dtype, CT, T1, T2, M, M, L, L, M, M, L * bl, 0, L * M, MM, 0, s);
         if (rc) return rc;
     }
     // the exchange must not start before earlier work on the caller's stream that R / X might still be read by
@@ -350,7 +350,7 @@ int qs_transform_two_body_sharded(void* comm, int dtype, const void* u_bslab, co
         if (n <= 0) return QS_OK;
         hipError_t ee = hipStreamWaitEvent(s, c->r_ready[k], 0);
         if (ee != hipSuccess) return hip_status(ee, "qs_transform_two_body_sharded: wait for rows");
-        return qs_matmul(dtype, Ct, at(R, lo * L * MM), at(out_pslab, lo * M * MM), M, MM, L, L, MM, MM, n, 0, L * MM,
+        return matmul_checked(dtype, Ct, at(R, lo * L * MM), at(out_pslab, lo * M * MM), M, MM, L, L, MM, MM, n, 0, L * MM,
                          M * MM, 0, s);
     };
     int op = 0;
@@ -358,7 +358,7 @@ int qs_transform_two_body_sharded(void* comm, int dtype, const void* u_bslab, co
         const int64_t slot0 = plan.chunk_slot0[k], rows_k = plan.chunk_slot0[k + 1] - slot0;
         // a:  X[slot, (b,r,s)] = CtX[slot, a] T2[a, (b,r,s)]   for the rows of chunk k
         if (bl > 0 && rows_k > 0) {
-            rc = qs_matmul(dtype, at(CtX, slot0 * L), T2, at(X, slot0 * row_x), rows_k, row_x, L, L, row_x, row_x, 1, 0, 0,
+            rc = matmul_checked(dtype, at(CtX, slot0 * L), T2, at(X, slot0 * row_x), rows_k, row_x, L, L, row_x, row_x, 1, 0, 0,
                            0, 0, s);
             if (rc) return rc;
         }
@@ -396,7 +396,7 @@ int qs_transform_two_body_sharded(void* comm, int dtype, const void* u_bslab, co
     e = hipEventRecord(c->done, c->stream);
     if (e == hipSuccess) e = hipStreamWaitEvent(s, c->done, 0);
     if (e != hipSuccess) return hip_status(e, "qs_transform_two_body_sharded: join");
-    note_dispatch("rccl grouped send/recv x%d chunks", nchunks);
+    note_dispatch("rccl grouped send/recv (%d chunks)", nchunks);
     return QS_OK;
 }
 

@@ -76,6 +76,11 @@ int gemm_c128(const double* A, const double* B, double* C, int64_t m, int64_t n,
               int64_t k, int64_t lda, int64_t ldb, int64_t ldc, int64_t batch,
               int64_t sa, int64_t sb, int64_t sc, int accumulate, hipStream_t stream);
 
+// qs_matmul's body without the reset of the dispatch record (qs_api.hip)
+int matmul_checked(int dtype, const void* A, const void* B, void* out, int64_t m, int64_t n, int64_t k, int64_t lda,
+                   int64_t ldb, int64_t ldc, int64_t batch, int64_t stride_a, int64_t stride_b, int64_t stride_c,
+                   int accumulate, hipStream_t stream);
+
 // VALU-free fast path, exact and edge forms (qs_gemm_fast.hip): QS_OK / error after launching, 1 = not eligible.
 int gemm_fast_try(int dtype, const double* A, const double* B, double* C, int64_t m, int64_t n,
                   int64_t k, int64_t lda, int64_t ldb, int64_t ldc, int64_t batch, int64_t sa,

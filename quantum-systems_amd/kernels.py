@@ -240,7 +240,9 @@ def transform_two_body_(u, C, C_tilde=None):
                                               work.numel(), L, M, _stream()),
             "qs_transform_two_body_inplace",
         )
-    return u.reshape(-1)[: M**4].reshape(M, M, M, M)
+    # (the tensor itself when the size does not change: no view object keeps a second handle on the storage, so
+    # the next change_basis can reuse it again)
+    return u if M == L else u.reshape(-1)[: M**4].reshape(M, M, M, M)
 
 
 class TransformPlan:
