@@ -637,9 +637,10 @@ def test_spin_squared_two_body_with_1024_spin_orbitals(K):
     for anti in (False, True):
         rows = K.spin_squared_two_body(S, antisymmetrize=anti, p_lo=700, p_hi=701)       # one row: 17 GB
         assert K.last_dispatch() == "qs::spin2_tb_kernel" and tuple(rows.shape) == (1, n, n, n)
-        for q in (0, 513, 1023):
+        scale = 3 * S.abs().max().item() ** 2
+        for q in (0, 513, 700, 1023):
             ref = sum(torch.outer(S[k, 700], S[k, q]) for k in range(3))                  # [r, s] = S[p,r] S[q,s]
             if anti:
-                ref = ref - sum(torch.outer(S[k, q], S[k, 700]) for k in range(3)).t()    # - S[p,s] S[q,r]
-            assert (rows[0, q] - ref).abs().max().item() <= 1e-12 * ref.abs().max().item()
+                ref = ref - sum(torch.outer(S[k, q], S[k, 700]) for k in range(3))        # - S[q,r] S[p,s]
+            assert (rows[0, q] - ref).abs().max().item() <= 1e-13 * scale
         del rows
