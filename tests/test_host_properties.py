@@ -71,4 +71,6 @@ def test_radial_integral_is_symmetric_and_matches_quadrature(n_p, m_p, n_q, m_q,
     assert np.isclose(a, b, rtol=1e-12, atol=1e-14)
     r = np.linspace(0, 40, 400001)
     f = r ** (1 + order) * td.spf_radial(r, n_p, m_p, 1.0, 0.9) * td.spf_radial(r, n_q, m_q, 1.0, 0.9)
-    np.testing.assert_allclose(a, np.trapezoid(f, r), rtol=1e-6, atol=1e-9)
+    # (the quadrature's own rounding grows with the size of the integrand: a selection-rule zero of the closed
+    # form comes out of it as ~1e-9 when int |f| ~ 1e3 -- found by this very test in round 2)
+    np.testing.assert_allclose(a, np.trapezoid(f, r), rtol=1e-6, atol=1e-9 + 1e-11 * np.trapezoid(np.abs(f), r))
