@@ -173,14 +173,15 @@ __global__ void kron_eye2_kernel(const TI* __restrict__ h, TO* __restrict__ out,
 // Two-body S^2 (basis_set.py:745-747, :525-526), complex128, n spin-orbitals:
 //   out[p,q,r,s] = sum_i S_i[p,r] S_i[q,s] - as * S_i[p,s] S_i[q,r]
 // accumulated in the reference's order i = x, y, z.  One workgroup per (p,q)
-// and 8 rows r; rows p and q of the three matrices are staged in LDS.
+// and a chunk of rows r (all of them when there are enough (p,q) pairs to fill the chip); rows p and q of the
+// three matrices are staged in LDS.
 // ----------------------------------------------------------------------------
 __device__ __forceinline__ f64x2 cmul(f64x2 a, f64x2 b) {
     return f64x2{a[0] * b[0] - a[1] * b[1], a[0] * b[1] + a[1] * b[0]};
 }
 
-__global__ __launch_bounds__(256) void spin2_tb_kernel(const f64x2* __restrict__ S, f64x2* __restrict__ out,
-                                                       int n, int p_lo, int rchunks, int as) {
+__global__ __launch_bounds__(1024) void spin2_tb_kernel(const f64x2* __restrict__ S, f64x2* __restrict__ out,
+                                                        int n, int p_lo, int rchunks, int rows_per_chunk, int cw, int as) {
     extern __shared__ __attribute__((aligned(16))) double smem_raw[];
     f64x2* sp = reinterpret_cast<f64x2*>(smem_raw);   // [3][n] rows p
     f64x2* sq = sp + 3 * n;                           // [3][n] rows q
@@ -197,14 +198,22 @@ __global__ __launch_bounds__(256) void spin2_tb_kernel(const f64x2* __restrict__
     }
     __syncthreads();
     f64x2* o = out + (pl * n + q) * (int64_t)n * n;
-    const int r_end = min(n, (rc + 1) * 8);
-    for (int r = rc * 8; r < r_end; ++r) {
-        for (int s = threadIdx.x; s < n; s += blockDim.x) {
+    const int r_end = min(n, (rc + 1) * rows_per_chunk);
+    // The workgroup is a (rows x cw columns) grid of threads: cw = the columns rounded up to whole waves (at most the
+    // workgroup), so a small n does not leave most lanes idle.  A lane keeps its column s for all its rows: S_i[q, s]
+    // (and S_i[p, s] for the exchange term) are read from LDS once per column, only the row factors S_i[p, r] /
+    // S_i[q, r] (one address per wave: a broadcast) per row.
+    const int ts = threadIdx.x % cw, tr = threadIdx.x / cw, rg = blockDim.x / cw;
+    for (int s = ts; s < n; s += cw) {
+        f64x2 qs[3], ps[3];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) { qs[k] = sq[k * n + s]; ps[k] = sp[k * n + s]; }
+        for (int r = rc * rows_per_chunk + tr; r < r_end; r += rg) {
             f64x2 v = f64x2{0.0, 0.0}, w = f64x2{0.0, 0.0};
 #pragma unroll
             for (int k = 0; k < 3; ++k) {
-                v = v + cmul(sp[k * n + r], sq[k * n + s]);
-                if (as) w = w + cmul(sp[k * n + s], sq[k * n + r]);
+                v = v + cmul(sp[k * n + r], qs[k]);
+                if (as) w = w + cmul(ps[k], sq[k * n + r]);
             }
             o[(int64_t)r * n + s] = as ? (v - w) : v;
         }
@@ -298,16 +307,28 @@ int kron_eye2(int in_dtype, int out_dtype, const void* h, void* out, int64_t nma
 
 int spin2_two_body(const void* S, void* out, int64_t n, int64_t p_lo, int64_t p_hi, int as,
                    hipStream_t stream) {
-    const int rchunks = (int)cdiv(n, 8);
-    const int64_t nwg = (p_hi - p_lo) * n * rchunks;
+    // one workgroup stages rows p and q of the three matrices (96 n bytes) and writes rows_per_chunk * n elements:
+    // whole (p, q) matrices per workgroup unless that leaves the chip short of workgroups (the first version
+    // always took 8 rows: 48 KB staged per 64 KB written at n = 512)
+    const int64_t npq = (p_hi - p_lo) * n;
+    int64_t want = cdiv(2048, npq);
+    if (want < 1) want = 1;
+    if (want > cdiv(n, 8)) want = cdiv(n, 8);
+    const int rows_per_chunk = (int)cdiv(n, want);
+    const int rchunks = (int)cdiv(n, rows_per_chunk);
+    const int64_t nwg = npq * rchunks;
     if (nwg >= (int64_t(1) << 31)) return QS_ERR_BAD_EXTENT;
     const size_t lds = sizeof(double) * 2 * 6 * n;       // rows p and q of S_x, S_y, S_z: 96 n bytes
     if (lds > 160 * 1024) return QS_ERR_BAD_EXTENT;      // n <= 1706 spin orbitals (LDS of one CU)
     static PerDeviceOnce lds_opt_in;                     // beyond 64 KB (n > 682) the kernel opts in, per device
     if (int rc = opt_in_dynamic_lds((const void*)spin2_tb_kernel, lds, lds_opt_in, "hipFuncSetAttribute(spin2_tb)"))
         return rc;
-    hipLaunchKernelGGL(spin2_tb_kernel, dim3((unsigned)nwg), dim3(256), lds, stream,
-                       (const f64x2*)S, (f64x2*)out, (int)n, (int)p_lo, rchunks, as);
+    // beyond 64 KB of LDS one workgroup fits a CU: make it 1024 threads so that the CU still has 16 waves in flight
+    const int threads = lds > 64 * 1024 ? 1024 : 256;
+    int cw = (int)(cdiv(n, 64) * 64);
+    if (cw > threads) cw = threads;
+    hipLaunchKernelGGL(spin2_tb_kernel, dim3((unsigned)nwg), dim3(threads), lds, stream,
+                       (const f64x2*)S, (f64x2*)out, (int)n, (int)p_lo, rchunks, rows_per_chunk, cw, as);
     note_dispatch("qs::spin2_tb_kernel");
     return launch_status("spin2_two_body launch");
 }
