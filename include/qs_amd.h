@@ -313,8 +313,9 @@ const char* qs_last_dispatch(void);
  *     the d and c contractions of a small-basis transform into one pass, 2 = one
  *     wave per slab always), "sandwich" (the two fused passes of a small-basis
  *     transform on the 4-wide fp64 matrix instruction: 0 = off, 1 = both,
- *     2 = the (d, c) pass only, 3 = the (b, a) pass only, 4 = both wherever the
- *     kernel is legal, not only where it measures faster), "sandwich_mode"
+ *     2 = the (d, c) pass only, 3 = the (b, a) pass only; 4 / 5 / 6 = both /
+ *     (d, c) only / (b, a) only wherever the kernel is legal, not only where it
+ *     measures faster), "sandwich_mode"
  *     (work split of those passes: -1 automatic, 0 one item quad per workgroup,
  *     1 four adjacent quads per workgroup, 3 the same with a barrier per step).
  *   qs_probe_mfma_f64: register-resident fp64 MFMA loop, `blocks` workgroups

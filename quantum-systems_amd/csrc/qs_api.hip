@@ -140,7 +140,7 @@ static int contract_dcb(int dtype, const void* u, const void* C, void* CT, const
     // small bases: d and c in one pass over the tensor (each slab u[a, b] is contiguous):
     //   T2[ab] = C^T . u[ab] . C   on the 4-wide matrix instruction, else on the 16-wide one
     int rc = 1;
-    if (g_tune.sandwich == 1 || g_tune.sandwich == 2 || g_tune.sandwich >= 4)
+    if (g_tune.sandwich == 1 || g_tune.sandwich == 2 || g_tune.sandwich == 4 || g_tune.sandwich == 5)
         rc = sandwich4_try(dtype, u, T2, C, M, 1, C, 1, M, rows * L, L, M, L * L, L, 1, M * M, M, 1, s);
     if (rc == 1) rc = slab_pair_try(dtype, u, C, T2, rows * L, L, M, s);
     if (rc == 1) {
@@ -257,17 +257,17 @@ int qs_transform_two_body(int dtype, const void* u, const void* C, const void* C
 
     // small bases: two passes over the tensor instead of four -- (d, c) per slab u[a, b], then (b, a) per
     // column (r, s): out[:, :, rs] = Ct . T2[:, :, rs] . Ct^T (the same k-ordered sums, element for element)
-    if (g_tune.sandwich == 1 || g_tune.sandwich == 3 || g_tune.sandwich >= 4) {
+    if (g_tune.sandwich == 1 || g_tune.sandwich == 3 || g_tune.sandwich == 4 || g_tune.sandwich == 6) {
         // T2 (L, L, M, M) goes to WA; the eligibility of the second pass is known before the first runs
         const int64_t MM = M * M;
         const int64_t n4 = cdiv(L, 4);
         const bool second_ok = dtype == QS_F64 && L <= 64 && M <= 64 && n4 == cdiv(M, 4) && MM >= 1024 &&
                                (4 * n4) * L * MM * 2 * 8 < (int64_t(1) << 31) &&
-                               (g_tune.sandwich >= 4 ? n4 >= 6 : (n4 >= 9 && n4 != 15 && !(M % 4 == 0 && M >= 52)));
+                               (g_tune.sandwich >= 4 ? n4 >= 6 : (n4 >= 9 && n4 != 15));
         if (second_ok) {
             void* T1s = (M < L) ? at(WA, wa, es) : out;     // scratch of the unfused fall-back of the first pass
             int rc2 = 1;
-            if (g_tune.sandwich != 3)
+            if (g_tune.sandwich != 3 && g_tune.sandwich != 6)
                 rc2 = sandwich4_try(dtype, u, WA, C, M, 1, C, 1, M, L * L, L, M, L * L, L, 1, MM, M, 1, s);
             if (rc2 == 1) {
                 // first pass on the 16-wide kernels (T1 in the spare buffer, T2 into WA)

@@ -22,11 +22,20 @@
 // Work split: a workgroup takes an item quad; its four waves (one per SIMD) take the column groups of R in
 // chunks of <= 4 groups and rotate the chunks from round to round (14 groups = 4 + 4 + 3 + 3 would otherwise
 // leave two SIMDs idle a quarter of the time).  Per chunk a wave keeps in registers: its fragments of R
-// (ceil(l/4) x 4), the output accumulators (ceil(l/4) x 4), a two-deep ring of In fragments loaded straight from
-// global memory two row quads ahead -- across chunk and item boundaries -- and reads the fragments of Lm from an
-// LDS table with compile-time offsets.  No VALU work, no barrier and no branch inside a chunk: addresses are
-// one lane offset (four variants: interior / last row quad / last column quad / both, with out-of-range lanes
-// parked past num_records so that the hardware returns 0.0 / drops the store) plus scalar offsets.
+// (ceil(l/4) x 4), the accumulators of Y (ceil(l/4) x 4), a two-deep ring of In fragments fetched three row quads
+// ahead -- across chunk and item boundaries -- and reads the fragments of Lm from an LDS table with compile-time
+// offsets.
+//
+// What the instruction stream of a one-wave SIMD may contain between two fp64 MFMAs without costing matrix-pipe
+// time (tools/probe_mfma4c.hip, cycles per MFMA with one extra instruction per three MFMAs: 16.5 alone):
+//   * one LDS read, or two (16.6); one LDS write (16.8) -- but a write and a read behind the same MFMA 22.1;
+//   * a vector memory instruction every OTHER group of three MFMAs (16.5; x2 or x4 dwords alike), every group 21.3:
+//     the CU's address unit takes one 64-lane instruction per ~16 cycles from its four waves;
+//   * s_waitcnt, SALU: free; s_nop n: n + 1 cycles; ANY VALU instruction (v_add_u32): 12 cycles.
+// Hence: fragments are fetched two at a time (16 bytes per lane), every memory instruction has an MFMA of its
+// own to hide behind (a sched_barrier after each), and the steady state has no VALU instruction: addresses are one
+// lane offset (variants: interior / last row quad / last k pair / both, with out-of-range lanes parked past
+// num_records so that the hardware returns 0.0 / drops the store) plus scalar offsets.
 // Algorithmic bytes per launch: 8 (L^2 + M^2) per item; roofline: HBM below l ~ 64 (the matrix pipe needs
 // 2 x 2 x ceil(l/4)^3 x 16 cycles per item quad per CU).
 
@@ -35,8 +44,8 @@
 #include "qs_common.h"
 
 // Development builds only (never defined in the shipped library): bit mask of parts to leave out, to find
-// what bounds the kernel.  1 fetch, 2 stores, 4 transit through LDS, 8 Lm fragment reads, 16 all MFMAs, 32 return
-// after the tables are built, 64 return at once
+// what bounds the kernel.  1 fetch, 2 stores, 16 all MFMAs, 32 return after the tables are built, 64 return at once,
+// 128 every fetch of a wave from the same addresses (L1 hits)
 #ifndef QS_S4_ABLATE
 #define QS_S4_ABLATE 0
 #endif
@@ -54,6 +63,8 @@ __device__ __forceinline__ void unroll(F&& f) {
 }
 
 typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef double f64x2 __attribute__((ext_vector_type(2)));
 
 #ifdef QS_S4_TRACE      // development: shader-clock stamps of one workgroup's wave 0 at every step (qs_s4_trace symbol)
 __device__ unsigned long long qs_s4_trace[4096];
@@ -89,7 +100,7 @@ struct S4Args {
     const double* R;      // R[k][j]  = R[k * r_sk + j * r_sj],   L x M
     const double* Lm;     // Lm[p][a] = Lm[p * l_sp + a * l_sa],  M x L
     int64_t r_sk, r_sj, l_sp, l_sa;
-    int64_t in_item, in_row, in_col;       // element strides of In_t[i][k]
+    int64_t in_item, in_row, in_col;       // element strides of In_t[i][k]: in_col == 1 (a slab) or in_item == 1 (a column)
     int64_t out_item, out_row, out_col;    // element strides of Out_t[p][j]
     int L, M;
     unsigned nitems, nquads;
@@ -104,13 +115,17 @@ __global__ __launch_bounds__(256, 1) void sandwich4_kernel(const S4Args g) {
     constexpr int NJ_BIG = (N4 + NCH - 1) / NCH;            // the first N4 % NCH chunks (all if it divides) have this many
     constexpr int NJ_SMALL = N4 / NCH;
     constexpr int N_BIG = (N4 % NCH) ? (N4 % NCH) : NCH;
+    constexpr int NP = (N4 + 1) / 2;                        // fragment pairs of a row quad (one 16-byte fetch each)
+    constexpr int NS = 2 * NP;                              // transit slots (the last one is a dummy when N4 is odd)
+    constexpr int NST = 2;                                  // row quads in flight between their fetch and the transit buffer
     static_assert(NCH <= 4 && NJ_BIG <= 4, "a workgroup has four waves");
-    static_assert(N4 >= 3, "the fetch runs three row quads ahead");
+    static_assert(N4 > NST + 1 && NJ_SMALL >= 3, "the fetch runs NST + 1 row quads ahead; three MFMAs per k quad carry its instructions");
 
     extern __shared__ __attribute__((aligned(16))) double lds[];
     double* rtab = lds;                    // [ks][jg][16]: R[4 ks + z][4 jg + x]  at z * 4 + x
     double* ltab = lds + N4 * N4 * 16;     // [pg][ka][16]: Lm[4 pg + x][4 ka + z] at z * 4 + x
-    double* transit = lds + 2 * N4 * N4 * 16;   // [wave][ks][64]: a row quad of In fragments on its way into MFMA lane order
+    double* transit = lds + 2 * N4 * N4 * 16;   // [wave][2][NS][64]: a row quad of In fragments on its way into MFMA
+                                                // lane order, and as many words nobody reads
     const int L = g.L, M = g.M;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -150,7 +165,7 @@ __global__ __launch_bounds__(256, 1) void sandwich4_kernel(const S4Args g) {
     };
     unsigned iq = quad_of(unit);
 
-    const unsigned ka_step = (unsigned)(4 * g.in_row * 8), ks_step = (unsigned)(4 * g.in_col * 8);
+    const unsigned ka_step = (unsigned)(4 * g.in_row * 8), pair_step = (unsigned)(8 * g.in_col * 8);
     const unsigned pg_step = (unsigned)(4 * g.out_row * 8), jg_step = (unsigned)(4 * g.out_col * 8);
 
     auto rsrc = [&](const double* base, unsigned quad, int64_t item_stride) __attribute__((always_inline)) {
@@ -163,38 +178,63 @@ __global__ __launch_bounds__(256, 1) void sandwich4_kernel(const S4Args g) {
     // An In fragment (A operand: row x, block y, k z) is FETCHED in memory order and put into MFMA lane order on
     // its way through LDS: the texture-address unit only merges ADJACENT lanes, and in the MFMA order adjacent
     // lanes are rows (d, c: 440 bytes apart) -- 64 separate accesses per instruction, which bound the first
-    // version of this kernel (TA 73 % busy, matrix pipe 38 %).  For the fetch, the lane digit that runs fastest
-    // takes the role whose stride is smallest (k for a slab: 32-byte runs; the item for a column: 32-byte runs).
-    int fr, fi, fk;          // role values (row, item, k in 0..3) of this lane when it fetches
-    {
-        const int d0 = lane & 3, d1 = (lane >> 2) & 3, d2 = lane >> 4;
-        const int64_t sr = g.in_row, si = g.in_item, sk = g.in_col;
-        // rank of each role's stride (0 = smallest); ties broken row < item < k
-        const int rank_r = (si < sr) + (sk < sr), rank_i = (sr <= si) + (sk < si), rank_k = (sr <= sk) + (si <= sk);
-        fr = rank_r == 0 ? d0 : rank_r == 1 ? d1 : d2;
-        fi = rank_i == 0 ? d0 : rank_i == 1 ? d1 : d2;
-        fk = rank_k == 0 ? d0 : rank_k == 1 ? d1 : d2;
+    // version of this kernel (TA 73 % busy, matrix pipe 38 %).  A fetch takes the two fragments of a k-quad pair,
+    // 16 bytes per lane along the index that is contiguous in memory:
+    //   slab   (in_col == 1):  lane = h + 4 row + 16 item;  k = 8 m + 2 h, 2 h + 1          (64-byte runs)
+    //   column (in_item == 1): lane = e + 2 k + 8 row + 32 f;  items 2 e, 2 e + 1 of fragment 2 m + f   (32-byte runs)
+    const bool slab = g.in_col == 1;
+    int f_row, f_par, f_item[2], f_k[2];     // this lane's two elements when it fetches: row, fragment of the pair, item, k
+    if (slab) {
+        const int h = lane & 3;
+        f_row = (lane >> 2) & 3; f_par = h >> 1;
+        f_item[0] = f_item[1] = lane >> 4;
+        f_k[0] = 2 * (h & 1); f_k[1] = f_k[0] + 1;
+    } else {
+        const int e = lane & 1;
+        f_row = (lane >> 3) & 3; f_par = lane >> 5;
+        f_item[0] = 2 * e; f_item[1] = 2 * e + 1;
+        f_k[0] = f_k[1] = (lane >> 1) & 3;
     }
-    // Position of element (row, item, k) of a fragment in its 512-byte transit slot: 128-byte line k, 8-byte bank
-    // pair (row ^ k) + 4 (item ^ k).  Any 16 lanes that go to LDS together -- (row, item) at fixed k when the MFMA
-    // lanes read, (k, row) at fixed item or (item, k) at fixed row when the fetch lanes write -- hit 16 different
-    // bank pairs; the plain lane order would put four lanes of every write on each bank.
-    auto slot_pos = [](int row, int item, int k) __attribute__((always_inline)) {
-        return (unsigned)(16 * k + ((row ^ k) + 4 * (item ^ k)));
+    // Position of element (row, item, k) of a fragment in its 512-byte transit slot (slot parity par): 128-byte line
+    // k, 8-byte bank pair (row ^ 2 (k & 1)) + 4 (item ^ ((k >> 1) | 2 par)).  Any 16 adjacent lanes that go to LDS
+    // together -- (row, item) at fixed k when the MFMA lanes read, either of the two fetch layouts when the fetch
+    // lanes write their first or their second element -- hit 16 different bank pairs (searched over the XOR masks
+    // that are linear in (k, par)); the plain lane order would put four lanes of every write on each bank.
+    auto slot_pos = [](int row, int item, int k, int par) __attribute__((always_inline)) {
+        return (unsigned)(16 * k + ((row ^ ((k & 1) << 1)) + 4 * (item ^ ((k >> 1) | (par << 1)))));
     };
-    const unsigned transit_wr = slot_pos(fr, fi, fk);
-    const unsigned transit_rd = slot_pos(lane & 3, (lane >> 2) & 3, lane >> 4);
-    double* const my_transit = transit + wave * (N4 * 64);
-    // lane offsets of a fetch.  Variant bit 0: last row quad, bit 1: last k quad.  A lane whose row / k / item
-    // does not exist is parked.
-    auto in_offsets = [&](unsigned quad, bool live, unsigned (&v)[4]) __attribute__((always_inline)) {
-        const unsigned base = (unsigned)((fr * g.in_row + fi * g.in_item + fk * g.in_col) * 8);
-        const bool item_ok = live && quad * 4 + fi < g.nitems;
-        const bool row_ok = rl == 0 || fr < rl, k_ok = rl == 0 || fk < rl;
-        v[0] = item_ok ? base : kParked;
-        v[1] = item_ok && row_ok ? base : kParked;
-        v[2] = item_ok && k_ok ? base : kParked;
-        v[3] = item_ok && row_ok && k_ok ? base : kParked;
+    double* const my_transit = transit + wave * (2 * NS * 64);
+    const unsigned rd_even = slot_pos(x, y, z, 0), rd_odd = slot_pos(x, y, z, 1);
+    // Lane offsets of a fetch (v: bit 0 last row quad, bit 1 last k pair) and where its two elements go in the transit
+    // buffer (w[0], w[1]; w[2], w[3] for the last k pair).  A lane whose row / k / item does not exist is parked (the
+    // hardware returns zeros).  A lane whose FIRST element exists and whose second does not -- the last k of an odd L
+    // in a slab, the last item of an odd item count in a column -- fetches 8 bytes earlier (memory that always
+    // exists), drops the first half into words nobody reads and puts the second half where the first belongs; the
+    // place of the missing element keeps the zero the buffer starts with (k) or belongs to a block whose results are
+    // never stored (item).  All offsets carry + 8 against a base pointer 8 bytes early, so that none is negative.
+    auto in_offsets = [&](unsigned quad, bool live, unsigned (&v)[4], unsigned (&w)[4]) __attribute__((always_inline)) {
+        const int64_t el = f_row * g.in_row + f_item[0] * g.in_item + (4 * f_par + f_k[0]) * g.in_col;
+        const unsigned base = (unsigned)(el * 8) + 8;
+        const bool row_ok = rl == 0 || f_row < rl;
+        const int k_last = 8 * (NP - 1) + 4 * f_par;             // first k of this lane's fragment in the last pair
+        const unsigned p0 = f_par * 64 + slot_pos(f_row, f_item[0], f_k[0], f_par);
+        const unsigned p1 = f_par * 64 + slot_pos(f_row, f_item[1], f_k[1], f_par);
+        const unsigned w_dump = NS * 64 + p0;                    // (the pair's offset is added to all of these)
+        // (one set of unconditional assignments: stores into the arrays from both sides of a branch leave them in
+        // scratch memory)
+        const bool i0_ok = live && quad * 4 + f_item[0] < g.nitems, i1_ok = quad * 4 + f_item[1] < g.nitems;
+        const bool e0_ok = k_last + f_k[0] < L, e1_ok = k_last + f_k[1] < L;
+        const bool shift_k = slab && e0_ok && !e1_ok, shift_i = !slab && i0_ok && !i1_ok;
+        const unsigned b_mid = i0_ok ? (shift_i ? base - 8 : base) : kParked;
+        const unsigned b_last = i0_ok && e0_ok ? (shift_k || shift_i ? base - 8 : base) : kParked;
+        v[0] = b_mid;
+        v[1] = row_ok ? b_mid : kParked;
+        v[2] = b_last;
+        v[3] = row_ok ? b_last : kParked;
+        w[0] = shift_i ? w_dump : p0;
+        w[1] = shift_i ? p0 : p1;
+        w[2] = shift_k || shift_i ? w_dump : p0;
+        w[3] = shift_k || shift_i ? p0 : p1;
     };
     // lane offsets of an Out fragment (D: row z, block y, column x).  Bit 0: last row quad, bit 1: last column quad
     auto out_offsets = [&](unsigned quad, unsigned (&v)[4]) __attribute__((always_inline)) {
@@ -208,46 +248,73 @@ __global__ __launch_bounds__(256, 1) void sandwich4_kernel(const S4Args g) {
     };
 
     double ring[2][N4];       // In fragments of two row quads in MFMA lane order: stage, register ks
-    double stg[2][N4];        // the same as fetched (memory lane order), on their way to the transit buffer
+    // the same as fetched (memory lane order), on their way to the transit buffer.  (Two row quads in flight: a fetch
+    // has two steps, ~1.1 us, to arrive, and the transit writes still wait ~110 cycles per step for the tensor.  Three
+    // or four stages spill: the stage of a row quad is (row quad + phase) % NST, the phase advances by N4 per item
+    // quad and every phase is one more copy of the chunk body.)
+    double stg[NST][NS];
 
-    // One fragment of row quad ka (k quad ks) is fetched with lane offset v (which carries the row quad: one
-    // VALU add per row quad) and scalar offset ks * ks_step (ceil(l/4) loop-invariant SGPRs).
-    auto fetch_frag = [&](auto rs, unsigned v, auto KS) __attribute__((always_inline)) {
-        if constexpr (QS_S4_ABLATE & 1) return 1.0 + decltype(KS)::value;
-        else
-        return __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(rs, (int)v, (int)(decltype(KS)::value * ks_step), 0));
+    // (s_row: the row quad's offset, made opaque once per step -- or the compiler keeps all ceil(l/4)^2 sums of row
+    // and pair offsets in SGPRs and spills them)
+    auto opaque = [](unsigned v) __attribute__((always_inline)) {
+        asm volatile("" : "+s"(v));
+        return v;
+    };
+    // the fragment pair m of a row quad: lane offset v, scalar offset row quad + pair
+    auto fetch_pair = [&](auto rs, unsigned v, unsigned s_row, auto MP, double& d0, double& d1) __attribute__((always_inline)) {
+        if constexpr (QS_S4_ABLATE & 1) { d0 = 1.0 + decltype(MP)::value; d1 = 0.5; }
+        else {
+            const unsigned s_off = (QS_S4_ABLATE & 128) ? 0u : s_row + decltype(MP)::value * pair_step;
+            const u32x4 q = __builtin_amdgcn_raw_buffer_load_b128(rs, (int)v, (int)s_off, 0);
+            const f64x2 d = __builtin_bit_cast(f64x2, q);
+            d0 = d.x; d1 = d.y;
+        }
     };
     auto fetch_quad_row = [&](auto rs, const unsigned (&v)[4], auto KA, auto STAGE) __attribute__((always_inline)) {
         constexpr int ka = decltype(KA)::value, st = decltype(STAGE)::value;
-        const unsigned v_mid = v[ka == N4 - 1 ? 1 : 0] + ka * ka_step;
-        const unsigned v_end = v[(ka == N4 - 1 ? 1 : 0) | 2] + ka * ka_step;      // last k quad
-        unroll<0, N4>([&](auto KS) __attribute__((always_inline)) {
-            stg[st][decltype(KS)::value] = fetch_frag(rs, decltype(KS)::value == N4 - 1 ? v_end : v_mid, KS);
+        const unsigned s_row = opaque(ka * ka_step);
+        unroll<0, NP>([&](auto MP) __attribute__((always_inline)) {
+            constexpr int m = decltype(MP)::value;
+            fetch_pair(rs, v[(ka == N4 - 1 ? 1 : 0) | (m == NP - 1 ? 2 : 0)], s_row, MP, stg[st][2 * m], stg[st][2 * m + 1]);
         });
     };
-    // fetched fragment -> transit buffer (each lane writes where the MFMA lane that wants its value will read)
-    // -> ring stage, lane-linear.  One wave, one buffer: LDS executes a wave's accesses in order, no barrier.
-    auto settle_quad_row = [&](auto FROM, auto TO) __attribute__((always_inline)) {
+    // fetched pair -> transit buffer (each lane writes where the MFMA lanes that want its values will read) -> ring
+    // stage, lane-linear.  One wave, one buffer: LDS executes a wave's accesses in order, no barrier.
+    auto settle_quad_row = [&](auto FROM, auto TO, const unsigned (&w)[4]) __attribute__((always_inline)) {
         constexpr int from = decltype(FROM)::value, to = decltype(TO)::value;
-        unroll<0, N4>([&](auto KS) __attribute__((always_inline)) {
-            my_transit[decltype(KS)::value * 64 + transit_wr] = stg[from][decltype(KS)::value];
+        unroll<0, NP>([&](auto MP) __attribute__((always_inline)) {
+            constexpr int m = decltype(MP)::value;
+            my_transit[m * 128 + w[m == NP - 1 ? 2 : 0]] = stg[from][2 * m];
+            my_transit[m * 128 + w[m == NP - 1 ? 3 : 1]] = stg[from][2 * m + 1];
         });
         unroll<0, N4>([&](auto KS) __attribute__((always_inline)) {
-            ring[to][decltype(KS)::value] = my_transit[decltype(KS)::value * 64 + transit_rd];
+            constexpr int ks = decltype(KS)::value;
+            ring[to][ks] = my_transit[ks * 64 + ((ks & 1) ? rd_odd : rd_even)];
         });
     };
 
-    // One chunk: NJ column groups starting at jg0 for the item quad behind (rs_in, v_in); the ring already
-    // holds row quads 0 and 1 of it.  While row quad ka multiplies, row quad ka + 2 is fetched -- of this item
-    // quad, or (the last two) of the next one, behind (rs_pf, v_pf).  P = parity of the ring stage of ka = 0.
-    // ONE body serves chunks of NJ and of NJ - 1 column groups: the last group rides in two blocks of their own
-    // per step that a narrow chunk (full == false, wave-uniform) branches around.  Two bodies would leave the ring
-    // and the in-flight fetch registers in different physical registers, and the copies at the merge cost a
-    // drain to vmcnt(0) plus ~90 moves per unit.
+    // One chunk: NJ column groups starting at jg0 for the item quad behind (rs_in, v_in, w_in), in two phases:
+    //   1. Y[ka] = In[ka] . R[:, own columns] for every row quad ka -- Y stays in the accumulators.  The ring already
+    //      holds row quad 0; while row quad ka multiplies, row quad ka + 1 passes through the transit buffer
+    //      and row quad ka + 1 + NST is fetched -- of this item quad, or (the last ones) of the next one, behind
+    //      (rs_pf, v_pf, w_pf).  Q = stage of row quad 0 in the fetch registers (for an odd N4 also its ring stage).
+    //   2. Out[pg] = sum_ka Lm[pg][ka] . Y[ka] for every row quad pg (Y is already in B-operand layout); a finished
+    //      row quad leaves during the next one's MFMAs.
+    // (The first version ran both products per ka and accumulated all of Out: every row of Out was finished in the
+    // last step, all workgroups of the chip reached it together, and the 29 MB burst drained at the HBM write rate
+    // -- 5-10k cycles per chunk with the matrix pipe idle.  Now the chip reads in phase 1 and writes in phase 2, both
+    // at ~2.5 TB/s.)
+    // ONE body serves chunks of NJ and of NJ - 1 column groups: the last group rides in blocks of its own that a
+    // narrow chunk (full == false, wave-uniform) branches around -- two row quads per block, so that its two MFMA
+    // chains alternate (a single chain waits 4 cycles per link).  Two bodies would leave the ring and the in-flight
+    // fetch registers in different physical registers, and the copies at the merge cost a drain to vmcnt(0) plus
+    // ~90 moves per unit.
     auto chunk = [&](auto NJC, auto PC, int jg0, bool full, auto rs_in, auto rs_out, const unsigned (&v_out)[4],
-                     auto rs_pf, const unsigned (&v_pf)[4], const unsigned (&v_in)[4]) __attribute__((always_inline)) {
-        constexpr int NJ = decltype(NJC)::value, P = decltype(PC)::value;
+                     auto rs_pf, const unsigned (&v_pf)[4], const unsigned (&w_pf)[4], const unsigned (&v_in)[4],
+                     const unsigned (&w_in)[4]) __attribute__((always_inline)) {
+        constexpr int NJ = decltype(NJC)::value, Q = decltype(PC)::value, P = (N4 & 1) ? Q & 1 : 0;
         constexpr int NJM = (NJ_BIG == NJ_SMALL) ? NJ : NJ - 1;      // groups every chunk has
+        constexpr int JX = NJ - 1;                                   // the group only a wide chunk has (if NJM < NJ)
         double bf[N4][NJ];
         unroll<0, N4>([&](auto KS) __attribute__((always_inline)) {
             unroll<0, NJ>([&](auto J) __attribute__((always_inline)) {
@@ -255,87 +322,120 @@ __global__ __launch_bounds__(256, 1) void sandwich4_kernel(const S4Args g) {
                     rtab[(decltype(KS)::value * N4 + jg0 + decltype(J)::value) * 16 + e_lane];
             });
         });
-        double acc2[N4][NJ];
-        // fragments of Lm for row quad ka; each register is refilled for row quad ka + 1 right after its last use
-        double lf[N4];
-        unroll<0, N4>([&](auto PG) __attribute__((always_inline)) {
-            lf[decltype(PG)::value] = ltab[(decltype(PG)::value * N4) * 16 + e_lane];
+        double Y[N4][NJ];
+        double lf[2][N4];       // fragments of Lm for row quads pg (stage pg & 1) and pg + 1
+        double ov[2][NJ];       // Out fragments of row quads pg and pg - 1
+        if constexpr (NJM < NJ) ov[0][JX] = ov[1][JX] = 0.0;
+        // lane offsets of the chunk's column groups, for the interior row quads and for the last one: chosen once per
+        // chunk (last column quad of the matrix / a group this chunk does not have)
+        unsigned vo[2][NJ];
+        unroll<0, NJ>([&](auto J) __attribute__((always_inline)) {
+            constexpr int j = decltype(J)::value;
+            const bool last_col = jg0 + j == N4 - 1;                  // wave-uniform
+            const bool absent = j >= NJM && !full;
+            vo[0][j] = absent ? kParked : v_out[last_col ? 2 : 0];
+            vo[1][j] = absent ? kParked : v_out[last_col ? 3 : 1];
         });
-        auto store_row = [&](auto PG) __attribute__((always_inline)) {
-            constexpr int pg = decltype(PG)::value;
-            const unsigned v_mid = v_out[pg == N4 - 1 ? 1 : 0] + pg * pg_step;
-            const unsigned v_end = v_out[(pg == N4 - 1 ? 1 : 0) | 2] + pg * pg_step;     // last column quad
-            unroll<0, NJ>([&](auto J) __attribute__((always_inline)) {
-                constexpr int j = decltype(J)::value;
-                const double val = acc2[pg][j];
-                const bool last_col = jg0 + j == N4 - 1;                  // wave-uniform
-                unsigned vo = last_col ? v_end : v_mid;
-                if (j >= NJM && !full) vo = kParked;                      // this chunk has no such group
-                if constexpr (QS_S4_ABLATE & 2) { if (val == 12345.678) my_transit[0] = val; }
-                else
-                __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, val), rs_out, (int)vo,
-                                                      (int)((jg0 + j) * jg_step), 0);
-            });
+        auto store_frag = [&](auto PG, auto J, unsigned s_row, const double (&src)[NJ]) __attribute__((always_inline)) {
+            constexpr int pg = decltype(PG)::value, j = decltype(J)::value;
+            const double val = src[j];
+            if constexpr (QS_S4_ABLATE & 2) { if (val == 12345.678) my_transit[0] = val; }
+            else
+            __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, val), rs_out, (int)vo[pg == N4 - 1][j],
+                                                  (int)(s_row + (jg0 + j) * jg_step), 0);
         };
-        // Every memory instruction of a step rides between MFMAs (one k quad / one row quad of MFMAs carries at most
-        // three of them); the sched_barriers keep the compiler from gathering them into one block, during which
-        // the matrix pipe of this one-wave SIMD would stand still.
+        // ---- phase 1.  Behind the MFMAs of an even k quad 2 m: the two transit writes of pair m (row quad ka + 1) and,
+        // into the registers they free, the fetch of pair m of row quad ka + 1 + NST; behind those of the odd k quad: the two
+        // ring reads of that pair (and, in the last step, the first fragments of Lm).
         unroll<0, N4>([&](auto KA) __attribute__((always_inline)) {
             constexpr int ka = decltype(KA)::value, st = (ka + P) & 1;
             QS_S4_STAMP(ka)
             if (step_barrier) __builtin_amdgcn_s_barrier();
-            constexpr bool pf_next = ka + 3 >= N4;             // the fetch already belongs to the next item quad
-            constexpr int ka_f = pf_next ? ka + 3 - N4 : ka + 3;
-            const unsigned vf_mid = (pf_next ? v_pf : v_in)[ka_f == N4 - 1 ? 1 : 0] + ka_f * ka_step;
-            const unsigned vf_end = (pf_next ? v_pf : v_in)[(ka_f == N4 - 1 ? 1 : 0) | 2] + ka_f * ka_step;
-            // ---- Y[ka rows][own columns] = In[ka rows][:] . R[:][own columns];   meanwhile row quad ka + 1
-            // (fetched two steps ago) goes into the transit buffer and row quad ka + 3 is fetched into its registers
-            double acc1[NJ];
-            unroll<0, N4>([&](auto KS) __attribute__((always_inline)) {
-                constexpr int ks = decltype(KS)::value;
-                unroll<0, NJM>([&](auto J) __attribute__((always_inline)) {
-                    constexpr int j = decltype(J)::value;
-                    acc1[j] = mfma4(ring[st][ks], bf[ks][j], ks == 0 ? 0.0 : acc1[j]);
-                });
-                if constexpr (!(QS_S4_ABLATE & 4)) my_transit[ks * 64 + transit_wr] = stg[st ^ 1][ks];
-                else ring[st ^ 1][ks] = stg[st ^ 1][ks];
-                if constexpr (pf_next) stg[st ^ 1][ks] = fetch_frag(rs_pf, ks == N4 - 1 ? vf_end : vf_mid, KS);
-                else stg[st ^ 1][ks] = fetch_frag(rs_in, ks == N4 - 1 ? vf_end : vf_mid, KS);
-                __builtin_amdgcn_sched_barrier(0);
-            });
-            if constexpr (NJM < NJ) {
-                if (full) {     // the last column group of a wide chunk: both products, no memory operation in between
+            constexpr int sa = (ka + 1 + Q) % NST;             // fetch stage of row quad ka + 1, refilled with ka + 1 + NST
+            constexpr bool pf_next = ka + 1 + NST >= N4;       // the fetch already belongs to the next item quad
+            constexpr int ka_f = pf_next ? ka + 1 + NST - N4 : ka + 1 + NST;
+            const unsigned (&vf)[4] = pf_next ? v_pf : v_in;
+            const unsigned (&ws)[4] = ka + 1 >= N4 ? w_pf : w_in;      // row quad ka + 1 is the next item quad's first
+            const unsigned s_row = opaque(ka_f * ka_step);
+            if constexpr (NJM < NJ && ((ka & 1) || ka == N4 - 1)) {
+                if (full) {     // ring[st ^ 1] still holds row quad ka - 1
                     unroll<0, N4>([&](auto KS) __attribute__((always_inline)) {
                         constexpr int ks = decltype(KS)::value;
-                        acc1[NJ - 1] = mfma4(ring[st][ks], bf[ks][NJ - 1], ks == 0 ? 0.0 : acc1[NJ - 1]);
-                    });
-                    unroll<0, N4>([&](auto PG) __attribute__((always_inline)) {
-                        constexpr int pg = decltype(PG)::value;
-                        acc2[pg][NJ - 1] = mfma4(lf[pg], acc1[NJ - 1], ka == 0 ? 0.0 : acc2[pg][NJ - 1]);
+                        if constexpr (ka & 1)
+                            Y[ka - 1][JX] = mfma4(ring[st ^ 1][ks], bf[ks][JX], ks == 0 ? 0.0 : Y[ka - 1][JX]);
+                        Y[ka][JX] = mfma4(ring[st][ks], bf[ks][JX], ks == 0 ? 0.0 : Y[ka][JX]);
                     });
                 }
                 __builtin_amdgcn_sched_barrier(0);
             }
-            QS_S4_STAMP(64 + ka)
-            // ---- Out[:][own columns] += Lm[:][ka rows] . Y[ka rows][own columns]   (Y straight from the accumulators);
-            // meanwhile row quad ka + 1 comes back from the transit buffer in MFMA lane order, the Lm fragments of
-            // row quad ka + 1 are read, and in the last step the finished rows of Out go out
-            unroll<0, N4>([&](auto PG) __attribute__((always_inline)) {
-                constexpr int pg = decltype(PG)::value;
+            unroll<0, N4>([&](auto KS) __attribute__((always_inline)) {
+                constexpr int ks = decltype(KS)::value, m = ks / 2;
                 unroll<0, NJM>([&](auto J) __attribute__((always_inline)) {
                     constexpr int j = decltype(J)::value;
-                    acc2[pg][j] = mfma4(lf[pg], acc1[j], ka == 0 ? 0.0 : acc2[pg][j]);
+                    Y[ka][j] = mfma4(ring[st][ks], bf[ks][j], ks == 0 ? 0.0 : Y[ka][j]);
+                    if constexpr (!(ks & 1)) {
+                        if constexpr (j == 0) my_transit[m * 128 + ws[m == NP - 1 ? 2 : 0]] = stg[sa][ks];
+                        if constexpr (j == 1) my_transit[m * 128 + ws[m == NP - 1 ? 3 : 1]] = stg[sa][ks + 1];
+                        if constexpr (j == 2) {
+                            const unsigned v = vf[(ka_f == N4 - 1 ? 1 : 0) | (m == NP - 1 ? 2 : 0)];
+                            if constexpr (pf_next) fetch_pair(rs_pf, v, s_row, std::integral_constant<int, m>{},
+                                                              stg[sa][ks], stg[sa][ks + 1]);
+                            else fetch_pair(rs_in, v, s_row, std::integral_constant<int, m>{}, stg[sa][ks],
+                                            stg[sa][ks + 1]);
+                        }
+                    } else {
+                        if constexpr (j == 0) ring[st ^ 1][ks - 1] = my_transit[(ks - 1) * 64 + rd_even];
+                        if constexpr (j == 1) ring[st ^ 1][ks] = my_transit[ks * 64 + rd_odd];
+                        if constexpr (j == 2 && ka == N4 - 1) {
+                            lf[0][ks - 1] = ltab[(ks - 1) * 16 + e_lane];
+                            lf[0][ks] = ltab[ks * 16 + e_lane];
+                        }
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
                 });
-                if constexpr (!(QS_S4_ABLATE & 4)) ring[st ^ 1][pg] = my_transit[pg * 64 + transit_rd];
-                if constexpr (ka + 1 < N4) {
-                    if constexpr (QS_S4_ABLATE & 8) lf[pg] = 0.5;
-                    else lf[pg] = ltab[(pg * N4 + ka + 1) * 16 + e_lane];
-                }
-                if constexpr (ka == N4 - 1 && pg >= 1) store_row(std::integral_constant<int, pg - 1>{});
+            });
+            if constexpr (N4 & 1) {      // the last pair has one fragment: no odd k quad behind it
+                ring[st ^ 1][N4 - 1] = my_transit[(N4 - 1) * 64 + rd_even];
+                if constexpr (ka == N4 - 1) lf[0][N4 - 1] = ltab[(N4 - 1) * 16 + e_lane];
                 __builtin_amdgcn_sched_barrier(0);
+            }
+        });
+        // ---- phase 2.  Behind the MFMAs of row quad ka of Y: the fragment of Lm for (pg + 1, ka); the stores of row quad
+        // pg - 1 go behind every other one (no more than one vector memory instruction per two groups of MFMAs).
+        unroll<0, N4>([&](auto PG) __attribute__((always_inline)) {
+            constexpr int pg = decltype(PG)::value, b = pg & 1;
+            QS_S4_STAMP(64 + pg)
+            const unsigned s_prev = opaque((pg ? pg - 1 : 0) * pg_step);
+            if constexpr (NJM < NJ && ((pg & 1) || pg == N4 - 1)) {
+                if (full) {     // lf[b ^ 1] still holds the fragments of row quad pg - 1
+                    unroll<0, N4>([&](auto KA) __attribute__((always_inline)) {
+                        constexpr int ka = decltype(KA)::value;
+                        if constexpr (pg & 1)
+                            ov[b ^ 1][JX] = mfma4(lf[b ^ 1][ka], Y[ka][JX], ka == 0 ? 0.0 : ov[b ^ 1][JX]);
+                        ov[b][JX] = mfma4(lf[b][ka], Y[ka][JX], ka == 0 ? 0.0 : ov[b][JX]);
+                    });
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            unroll<0, N4>([&](auto KA) __attribute__((always_inline)) {
+                constexpr int ka = decltype(KA)::value;
+                unroll<0, NJM>([&](auto J) __attribute__((always_inline)) {
+                    constexpr int j = decltype(J)::value;
+                    ov[b][j] = mfma4(lf[b][ka], Y[ka][j], ka == 0 ? 0.0 : ov[b][j]);
+                    if constexpr (j == 0 && pg + 1 < N4) lf[b ^ 1][ka] = ltab[((pg + 1) * N4 + ka) * 16 + e_lane];
+                    if constexpr (j == 1 && pg >= 1 && (ka & 1) && ka / 2 < NJ)
+                        store_frag(std::integral_constant<int, pg - 1>{}, std::integral_constant<int, (ka / 2) % NJ>{},
+                                   s_prev, ov[b ^ 1]);
+                    __builtin_amdgcn_sched_barrier(0);
+                });
             });
         });
-        store_row(std::integral_constant<int, N4 - 1>{});
+        {
+            const unsigned s_row = opaque((N4 - 1) * pg_step);
+            unroll<0, NJ>([&](auto J) __attribute__((always_inline)) {
+                store_frag(std::integral_constant<int, N4 - 1>{}, J, s_row, ov[(N4 - 1) & 1]);
+            });
+        }
         __builtin_amdgcn_sched_barrier(0);
         QS_S4_STAMP(255)
     };
@@ -345,12 +445,9 @@ __global__ __launch_bounds__(256, 1) void sandwich4_kernel(const S4Args g) {
         return c < N_BIG ? c * NJ_BIG : N_BIG * NJ_BIG + (c - N_BIG) * NJ_SMALL;
     };
 
-    unsigned v_in[4], v_nx[4], v_out[4];
-    auto rs_in = rsrc(g.in, iq < g.nquads ? iq : 0, g.in_item);
-    in_offsets(iq, !idle && iq < g.nquads, v_in);
-    // the first fetches go out before the tables are built: the two latencies overlap
-    fetch_quad_row(rs_in, v_in, std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{});
-    fetch_quad_row(rs_in, v_in, std::integral_constant<int, 1>{}, std::integral_constant<int, 1>{});
+    unsigned v_in[4], v_nx[4], w_in[4], w_nx[4], v_out[4];
+    auto rs_in = rsrc(g.in - 1, iq < g.nquads ? iq : 0, g.in_item);
+    in_offsets(iq, !idle && iq < g.nquads, v_in, w_in);
     {   // every thread issues all its loads before the first LDS write (a load-store-load chain would pay the
         // memory latency ceil(l/4)^2/16 times before the first MFMA)
         constexpr int NF = (N4 * N4 * 16 + 255) / 256;
@@ -365,6 +462,15 @@ __global__ __launch_bounds__(256, 1) void sandwich4_kernel(const S4Args g) {
             rv[i] = (in && k < L && j < M) ? g.R[k * g.r_sk + j * g.r_sj] : 0.0;
             lv[i] = (in && p < M && a < L) ? g.Lm[p * g.l_sp + a * g.l_sa] : 0.0;
         }
+        // the first fetches go out before the tables are built: the two latencies overlap.  They follow the table
+        // loads (which every workgroup finds in L2): loads return in order, and the first touch of the tensor -- all
+        // workgroups at once -- would otherwise stand in front of the tables
+        __builtin_amdgcn_sched_barrier(0);
+        fetch_quad_row(rs_in, v_in, std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{});
+        fetch_quad_row(rs_in, v_in, std::integral_constant<int, 1>{}, std::integral_constant<int, 1>{});
+        __builtin_amdgcn_sched_barrier(0);
+        // the transit buffers start as zeros (the place of a k that does not exist is never written)
+        for (int i = tid; i < 4 * 2 * NS * 64; i += 256) transit[i] = 0.0;
 #pragma unroll
         for (int i = 0; i < NF; ++i) {
             const int f = tid + 256 * i;
@@ -377,36 +483,38 @@ __global__ __launch_bounds__(256, 1) void sandwich4_kernel(const S4Args g) {
     QS_S4_STAMP(254)
 
     QS_S4_STAMP(254)
-    settle_quad_row(std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{});
-    fetch_quad_row(rs_in, v_in, std::integral_constant<int, 2>{}, std::integral_constant<int, 0>{});
+    settle_quad_row(std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{}, w_in);
+    unroll<2, NST + 1>([&](auto R) __attribute__((always_inline)) {
+        fetch_quad_row(rs_in, v_in, R, std::integral_constant<int, decltype(R)::value % NST>{});
+    });
 
-    unsigned parity = 0;      // ring stage of row quad 0 of the current unit (alternates when N4 is odd)
+    unsigned phase = 0;       // fetch stage of row quad 0 of the current unit
     for (unsigned round = 0; unit < u_end; ++round) {
         const unsigned nu = unit + slots;
         const unsigned nq = nu < u_end ? quad_of(nu) : g.nquads;
         const bool more = nq < g.nquads;
-        auto rs_nx = rsrc(g.in, more ? nq : 0, g.in_item);
-        in_offsets(nq, more, v_nx);
+        auto rs_nx = rsrc(g.in - 1, more ? nq : 0, g.in_item);
+        in_offsets(nq, more, v_nx, w_nx);
         auto rs_out = rsrc(g.out, iq < g.nquads ? iq : 0, g.out_item);
         out_offsets(iq, v_out);
         const int c = chunk_of(unit, round);
         const int jg0 = chunk_first(c);
         const bool big = c < N_BIG;
-        if constexpr (N4 % 2 == 0) {
-            chunk(std::integral_constant<int, NJ_BIG>{}, std::integral_constant<int, 0>{}, jg0, big, rs_in, rs_out, v_out,
-                  rs_nx, v_nx, v_in);
-        } else {
-            if (parity) chunk(std::integral_constant<int, NJ_BIG>{}, std::integral_constant<int, 1>{}, jg0, big, rs_in,
-                              rs_out, v_out, rs_nx, v_nx, v_in);
-            else chunk(std::integral_constant<int, NJ_BIG>{}, std::integral_constant<int, 0>{}, jg0, big, rs_in, rs_out,
-                       v_out, rs_nx, v_nx, v_in);
-            parity ^= 1;
+        auto run = [&](auto QC) __attribute__((always_inline)) {
+            chunk(std::integral_constant<int, NJ_BIG>{}, QC, jg0, big, rs_in, rs_out, v_out, rs_nx, v_nx, w_nx, v_in, w_in);
+        };
+        if constexpr (N4 % NST == 0) run(std::integral_constant<int, 0>{});
+        else {
+            if (phase == 0) run(std::integral_constant<int, 0>{});
+            else if (phase == 1 || NST == 2) run(std::integral_constant<int, 1>{});
+            else run(std::integral_constant<int, 2 % NST>{});
+            phase = (phase + N4) % NST;
         }
         unit = nu;
         iq = nq;
         rs_in = rs_nx;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) v_in[i] = v_nx[i];
+        for (int i = 0; i < 4; ++i) { v_in[i] = v_nx[i]; w_in[i] = w_nx[i]; }
     }
     QS_S4_TRACE_DONE
 }
@@ -422,7 +530,7 @@ static int launch_sandwich4(const S4Args& g, hipStream_t stream) {
     if (wgs < gran) wgs = gran;
     const int64_t need = (units + gran - 1) / gran * gran;
     if (wgs > need) wgs = need;                          // short item lists: no idle workgroups
-    const size_t lds = sizeof(double) * (2 * N4 * N4 * 16 + 4 * N4 * 64);
+    const size_t lds = sizeof(double) * (2 * N4 * N4 * 16 + 4 * 2 * (2 * ((N4 + 1) / 2)) * 64);
     static PerDeviceOnce lds_opt_in;
     if (int rc = opt_in_dynamic_lds((const void*)sandwich4_kernel<N4>, lds, lds_opt_in, "hipFuncSetAttribute(sandwich4)"))
         return rc;
@@ -440,16 +548,15 @@ int sandwich4_try(int dtype, const void* in, void* out, const void* R, int64_t r
     const int n4 = (int)cdiv(L, 4);
     if (n4 != (int)cdiv(M, 4)) return 1;                 // (near-)square products only
     if (nitems < 1024 || nitems >= (int64_t(1) << 31)) return 1;    // enough item quads to occupy the chip
+    if (in_col != 1 && in_item != 1) return 1;           // the fetch takes 16 contiguous bytes per lane along k or the item
     // Where this kernel measures faster than the 16-wide path (same-box sweep over l = 21 ... 64,
-    // profiles/r02_small_basis.txt; g_tune.sandwich >= 4 overrides for tuning runs):
-    //   * ceil(l/4) = 15 spills registers (two chunk bodies per parity x 15 x 4 accumulators) and loses;
-    //   * contiguous items (the (d, c) pass) lose for ceil(l/4) in {8, 11, 12};
-    //   * interleaved items (the (b, a) pass): when l is a multiple of 4 from 52 up, the 16 runs of a fetch are
-    //     25 KB and 1.4 MB apart in whole 128-byte lines and pile up on a quarter of the L2 channels.
+    // profiles/r02_small_basis_sweep.txt; g_tune.sandwich >= 4 overrides for tuning runs):
+    //   * ceil(l/4) = 15 spills registers (two chunk bodies for the parity of the ring x 15 x 4 accumulators) and loses;
+    //   * below ceil(l/4) = 9 the transform is launch-bound either way;
+    //   * contiguous items (the (d, c) pass) lose for ceil(l/4) in {11, 12}.
     if (g_tune.sandwich < 4) {
         if (n4 == 15 || n4 < 9) return 1;
         if (in_item != 1 && (n4 == 11 || n4 == 12)) return 1;
-        if (in_item == 1 && (M % 4 == 0) && M >= 52) return 1;
     }
     // every byte offset inside an item quad stays below 2^31
     const int64_t in_span = (3 * in_item + (4 * n4) * (in_row > in_col ? in_row : in_col) * 2) * 8;

@@ -27,7 +27,8 @@ for l in ls:
     C, _ = torch.linalg.qr(torch.randn(l, l, dtype=torch.float64, device="cuda", generator=g))
     C = C.contiguous(); Ct = C.t().contiguous()
     out = {}
-    MODES = (0, 1, 2, 3) if len(ls) > 8 else (0, 1, 2, 3, 10, 11, 13)
+    # 0 the 16-wide path, 1 automatic; forced wherever the kernel exists: 4 both passes, 5 (d, c) only, 6 (b, a) only
+    MODES = (0, 1, 4, 5, 6) if len(ls) > 8 else (0, 1, 2, 3, 4, 10, 11, 13)
     for mode in MODES:
         if mode >= 10:
             K.tuning_set("sandwich", 1); K.tuning_set("sandwich_mode", mode - 10)
