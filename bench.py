@@ -328,21 +328,35 @@ class _StdoutToStderr:
 def timed_steps(torch, step, steps, warmup, barrier):
     """W untimed warm-up steps, then EXACTLY K steps bracketed by barrier + synchronize on both sides.
     Returns (wall seconds for the K steps, device seconds between the first and last event, per-step device
-    milliseconds from HIP events recorded on the launch stream around every step, last result)."""
+    milliseconds from HIP events recorded on the launch stream, last result).  Steps of a millisecond or more get an
+    event each; shorter ones (the l = 55 transform is two 50 us kernels) one event per ten steps, the per-step figures
+    then being tenths of a group: an event between two such steps costs ~10 % of the step."""
     res = None
+    torch.cuda.synchronize()
+    w0 = time.perf_counter()
     for i in range(warmup):
         res = step(i)
+    torch.cuda.synchronize()
+    est = (time.perf_counter() - w0) / max(warmup, 1)
+    stride = 1 if (warmup == 0 or est >= 1e-3 or steps < 20) else 10
     barrier()
-    evs = [torch.cuda.Event(enable_timing=True) for _ in range(steps + 1)]
+    marks = list(range(0, steps, stride)) + [steps]
+    evs = [torch.cuda.Event(enable_timing=True) for _ in marks]
     t0 = time.perf_counter()
     evs[0].record()
+    nxt = 1
     for i in range(steps):
         res = step(warmup + i)
-        evs[i + 1].record()
+        if i + 1 == marks[nxt]:
+            evs[nxt].record()
+            nxt += 1
     barrier()
     elapsed = time.perf_counter() - t0
-    per_step = [evs[i].elapsed_time(evs[i + 1]) for i in range(steps)]
-    return elapsed, evs[0].elapsed_time(evs[steps]) * 1e-3, per_step, res
+    per_step = []
+    for a in range(len(marks) - 1):
+        n = marks[a + 1] - marks[a]
+        per_step += [evs[a].elapsed_time(evs[a + 1]) / n] * n
+    return elapsed, evs[0].elapsed_time(evs[-1]) * 1e-3, per_step, res
 
 
 def median(xs):

@@ -449,18 +449,31 @@ __global__ __launch_bounds__(256, 1) void sandwich4_kernel(const S4Args g) {
     auto rs_in = rsrc(g.in - 1, iq < g.nquads ? iq : 0, g.in_item);
     in_offsets(iq, !idle && iq < g.nquads, v_in, w_in);
     {   // every thread issues all its loads before the first LDS write (a load-store-load chain would pay the
-        // memory latency ceil(l/4)^2/16 times before the first MFMA)
-        constexpr int NF = (N4 * N4 * 16 + 255) / 256;
+        // memory latency ceil(l/4)^2/16 times before the first MFMA).  Thread t takes element t & 15 of the 4 x 4
+        // blocks t / 16, t / 16 + 16, ...: the block coordinates advance by additions (the first version spent
+        // ~3.5k cycles here on 64-bit multiply-adds and divisions by N4), and a block or element that does not exist
+        // is a parked buffer offset that reads 0.0.
+        constexpr int NF = (N4 * N4 + 15) / 16;
+        const auto rs_R = rsrc(g.R, 0, 0), rs_L = rsrc(g.Lm, 0, 0);
+        const int ez = (tid >> 2) & 3, ex = tid & 3, b0 = tid >> 4;        // b0 < 16 <= 3 N4
+        int hi = (b0 >= N4) + (b0 >= 2 * N4), lo = b0 - hi * N4;
+        const int r_sk = (int)g.r_sk, r_sj = (int)g.r_sj, l_sp = (int)g.l_sp, l_sa = (int)g.l_sa;
+        int off_r = (4 * hi + ez) * r_sk + (4 * lo + ex) * r_sj;           // R[4 hi + ez][4 lo + ex]
+        int off_l = (4 * hi + ex) * l_sp + (4 * lo + ez) * l_sa;           // Lm[4 hi + ex][4 lo + ez]
         double rv[NF], lv[NF];
 #pragma unroll
         for (int i = 0; i < NF; ++i) {
-            const int f = tid + 256 * i;
-            const int blk = f >> 4, e = f & 15, hi = blk / N4, lo = blk % N4, ez = e >> 2, ex = e & 3;
-            const int k = 4 * hi + ez, j = 4 * lo + ex;
-            const int p = 4 * hi + ex, a = 4 * lo + ez;
-            const bool in = f < N4 * N4 * 16;
-            rv[i] = (in && k < L && j < M) ? g.R[k * g.r_sk + j * g.r_sj] : 0.0;
-            lv[i] = (in && p < M && a < L) ? g.Lm[p * g.l_sp + a * g.l_sa] : 0.0;
+            const bool in = hi < N4;
+            const bool r_ok = in && 4 * hi + ez < L && 4 * lo + ex < M, l_ok = in && 4 * hi + ex < M && 4 * lo + ez < L;
+            rv[i] = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(rs_R, r_ok ? off_r * 8 : (int)kParked, 0, 0));
+            lv[i] = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(rs_L, l_ok ? off_l * 8 : (int)kParked, 0, 0));
+            hi += 16 / N4; lo += 16 % N4;
+            off_r += (16 / N4) * 4 * r_sk + (16 % N4) * 4 * r_sj;
+            off_l += (16 / N4) * 4 * l_sp + (16 % N4) * 4 * l_sa;
+            const bool wrap = lo >= N4;
+            lo -= wrap ? N4 : 0; hi += wrap;
+            off_r += wrap ? 4 * r_sk - N4 * 4 * r_sj : 0;
+            off_l += wrap ? 4 * l_sp - N4 * 4 * l_sa : 0;
         }
         // the first fetches go out before the tables are built: the two latencies overlap.  They follow the table
         // loads (which every workgroup finds in L2): loads return in order, and the first touch of the tensor -- all
@@ -469,8 +482,8 @@ __global__ __launch_bounds__(256, 1) void sandwich4_kernel(const S4Args g) {
         fetch_quad_row(rs_in, v_in, std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{});
         fetch_quad_row(rs_in, v_in, std::integral_constant<int, 1>{}, std::integral_constant<int, 1>{});
         __builtin_amdgcn_sched_barrier(0);
-        // the transit buffers start as zeros (the place of a k that does not exist is never written)
-        for (int i = tid; i < 4 * 2 * NS * 64; i += 256) transit[i] = 0.0;
+        // the slots of the last k pair start as zeros (the place of a k that does not exist is never written)
+        for (int i = tid; i < 4 * 128; i += 256) transit[(i >> 7) * (2 * NS * 64) + (NS - 2) * 64 + (i & 127)] = 0.0;
 #pragma unroll
         for (int i = 0; i < NF; ++i) {
             const int f = tid + 256 * i;
