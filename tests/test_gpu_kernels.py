@@ -610,6 +610,32 @@ def test_sandwich_pass_keeps_non_finite_values_in_their_slabs(K):
     np.testing.assert_allclose(rest, ref, rtol=1e-11, atol=1e-11)
 
 
+@pytest.mark.parametrize("L", [33, 43, 53, 55, 63])
+def test_sandwich_reads_nothing_outside_the_tensor(K, L):
+    # The fetch takes 16 bytes per lane; a lane whose second element does not exist (the last k of an odd l in a slab,
+    # the last item of an odd item count in a column) fetches 8 bytes earlier instead of 8 bytes past the end.  With
+    # NaNs directly in front of and behind u (and behind the result buffer) the transform must not change by a bit.
+    g = torch.Generator(device="cuda:0").manual_seed(L)
+    n = L ** 4
+    pad = 64
+    big = torch.full((n + 2 * pad,), float("nan"), dtype=torch.float64, device="cuda:0")
+    u = big[pad:pad + n].view(L, L, L, L)
+    u.copy_(torch.rand(L, L, L, L, dtype=torch.float64, device="cuda:0", generator=g) - 0.5)
+    C = torch.randn(L, L, dtype=torch.float64, device="cuda:0", generator=g) / np.sqrt(L)
+    Ct = torch.randn(L, L, dtype=torch.float64, device="cuda:0", generator=g) / np.sqrt(L)
+    alone = u.clone()
+    with K.tuning(sandwich=0):
+        ref = K.transform_two_body(alone, C, Ct)
+    obig = torch.full((n + 2 * pad,), float("nan"), dtype=torch.float64, device="cuda:0")
+    out = obig[pad:pad + n].view(L, L, L, L)
+    with K.tuning(sandwich=4):
+        K.transform_two_body(u, C, Ct, out=out)
+        assert K.last_dispatch() == f"qs::sandwich4_kernel<{-(-L // 4)}> x2"
+    assert torch.equal(out, ref)
+    assert torch.isnan(obig[:pad]).all() and torch.isnan(obig[pad + n:]).all()      # nothing written outside either
+    assert torch.isnan(big[:pad]).all() and torch.isnan(big[pad + n:]).all()
+
+
 def test_replicated_layout_matches_full_transform(K):
     # sharded.transform_two_body_replicated on one GPU, every rank's slab (uses the skinny product)
     from quantum_systems_amd import sharded
