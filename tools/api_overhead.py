@@ -1,0 +1,38 @@
+"""API-level cost of change_basis at small l: wall time per call against the time of the u kernels alone."""
+import os
+import sys
+import time
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import quantum_systems_amd as qs  # noqa: E402
+from quantum_systems_amd import kernels as K  # noqa: E402
+
+l = int(sys.argv[1]) if len(sys.argv) > 1 else 55
+bs = qs.RandomBasisSet(l, 2, np=qs.hip)
+g = torch.Generator(device="cuda").manual_seed(3)
+C, _ = torch.linalg.qr(torch.randn(l, l, dtype=torch.float64, device="cuda", generator=g))
+C = C.contiguous()
+for _ in range(3):
+    bs.change_basis(C)
+torch.cuda.synchronize()
+n = 50
+t0 = time.perf_counter()
+for _ in range(n):
+    bs.change_basis(C)
+torch.cuda.synchronize()
+t_api = (time.perf_counter() - t0) / n
+u = bs.u
+Ct = C.conj().T.contiguous()
+out = torch.empty_like(torch.as_tensor(u))
+ut = torch.as_tensor(u)
+for _ in range(3):
+    K.transform_two_body(ut, C, Ct, out=out)
+torch.cuda.synchronize()
+t0 = time.perf_counter()
+for _ in range(n):
+    K.transform_two_body(ut, C, Ct, out=out)
+torch.cuda.synchronize()
+t_k = (time.perf_counter() - t0) / n
+print(f"l={l}: change_basis {t_api * 1e6:.0f} us per call; the two-body transform alone {t_k * 1e6:.0f} us")
