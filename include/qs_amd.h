@@ -317,7 +317,10 @@ const char* qs_last_dispatch(void);
  *     (d, c) only / (b, a) only wherever the kernel is legal, not only where it
  *     measures faster), "sandwich_mode"
  *     (work split of those passes: -1 automatic, 0 one item quad per workgroup,
- *     1 four adjacent quads per workgroup, 3 the same with a barrier per step).
+ *     1 four adjacent quads per workgroup, 3 the same with a barrier per step),
+ *     "sandwich_t2" (the intermediate between those passes stored transposed,
+ *     (r, s, a, b), so that the second pass fetches slabs too: -1 automatic,
+ *     0 never, 1 always).
  *   qs_probe_mfma_f64: register-resident fp64 MFMA loop, `blocks` workgroups
  *     of 4 waves, each wave issuing iters*8 v_mfma_f64_16x16x4_f64
  *     (flops = blocks*4*iters*8*2048); `sink` is a device scratch of

@@ -199,6 +199,7 @@ int qs_tuning_set(const char* key, int64_t value) {
     if (!strcmp(key, "gemm_fast_shape")) { g_tune.gemm_fast_shape = (int)value; return QS_OK; }
     if (!strcmp(key, "sandwich")) { g_tune.sandwich = (int)value; return QS_OK; }
     if (!strcmp(key, "sandwich_mode")) { g_tune.sandwich_mode = (int)value; return QS_OK; }
+    if (!strcmp(key, "sandwich_t2")) { g_tune.sandwich_t2 = (int)value; return QS_OK; }
     return QS_ERR_BAD_EXTENT;
 }
 
@@ -267,8 +268,20 @@ int qs_transform_two_body(int dtype, const void* u, const void* C, const void* C
         if (second_ok) {
             void* T1s = (M < L) ? at(WA, wa, es) : out;     // scratch of the unfused fall-back of the first pass
             int rc2 = 1;
-            if (g_tune.sandwich != 3 && g_tune.sandwich != 6)
-                rc2 = sandwich4_try(dtype, u, WA, C, M, 1, C, 1, M, L * L, L, M, L * L, L, 1, MM, M, 1, s);
+            // T2 transposed, (r, s, a, b): the second pass then fetches slabs like the first (64-byte runs, the four
+            // waves of a workgroup on the same lines) instead of columns (32-byte runs), and the first one stores the
+            // way the second does.  Same-box sweep (profiles/r02_small_basis_sweep.txt): 4-10 % faster for
+            // ceil(l/4) in {10, 13, 14, 16}, faster than the second pass alone for 11, slower for 9 and 12.
+            const bool want_t2 = g_tune.sandwich_t2 >= 0 ? g_tune.sandwich_t2 != 0
+                                                         : (n4 == 10 || n4 == 11 || n4 == 13 || n4 == 14 || n4 == 16);
+            bool t2_transposed = false;
+            if (g_tune.sandwich != 3 && g_tune.sandwich != 6) {
+                if (want_t2)
+                    rc2 = sandwich4_try(dtype, u, WA, C, M, 1, C, 1, M, L * L, L, M, L * L, L, 1, 1, M * L * L, L * L, s);
+                else
+                    rc2 = sandwich4_try(dtype, u, WA, C, M, 1, C, 1, M, L * L, L, M, L * L, L, 1, MM, M, 1, s);
+                t2_transposed = want_t2 && rc2 != 1;
+            }
             if (rc2 == 1) {
                 // first pass on the 16-wide kernels (T1 in the spare buffer, T2 into WA)
                 rc2 = slab_pair_try(dtype, u, C, WA, L * L, L, M, s);
@@ -281,7 +294,10 @@ int qs_transform_two_body(int dtype, const void* u, const void* C, const void* C
                 }
             }
             if (rc2) return rc2;
-            rc2 = sandwich4_try(dtype, WA, out, Ct, 1, L, Ct, L, 1, MM, L, M, 1, L * MM, MM, 1, M * MM, MM, s);
+            if (t2_transposed)
+                rc2 = sandwich4_try(dtype, WA, out, Ct, 1, L, Ct, L, 1, MM, L, M, L * L, L, 1, 1, M * MM, MM, s);
+            else
+                rc2 = sandwich4_try(dtype, WA, out, Ct, 1, L, Ct, L, 1, MM, L, M, 1, L * MM, MM, 1, M * MM, MM, s);
             if (rc2 != 1) return rc2;
             return QS_ERR_HIP;    // unreachable: the second pass was checked eligible above
         }

@@ -566,10 +566,12 @@ int sandwich4_try(int dtype, const void* in, void* out, const void* R, int64_t r
     // profiles/r02_small_basis_sweep.txt; g_tune.sandwich >= 4 overrides for tuning runs):
     //   * ceil(l/4) = 15 spills registers (two chunk bodies for the parity of the ring x 15 x 4 accumulators) and loses;
     //   * below ceil(l/4) = 9 the transform is launch-bound either way;
-    //   * contiguous items (the (d, c) pass) lose for ceil(l/4) in {11, 12}.
+    //   * slabs in, slabs out (the (d, c) pass with T2 in its natural layout) lose for ceil(l/4) in {11, 12};
+    //   * slabs in, interleaved items out (either pass when T2 is stored transposed) lose for ceil(l/4) = 12.
     if (g_tune.sandwich < 4) {
         if (n4 == 15 || n4 < 9) return 1;
-        if (in_item != 1 && (n4 == 11 || n4 == 12)) return 1;
+        if (in_item != 1 && out_item != 1 && (n4 == 11 || n4 == 12)) return 1;
+        if (in_item != 1 && out_item == 1 && n4 == 12) return 1;
     }
     // every byte offset inside an item quad stays below 2^31
     const int64_t in_span = (3 * in_item + (4 * n4) * (in_row > in_col ? in_row : in_col) * 2) * 8;

@@ -567,8 +567,10 @@ def test_sandwich_passes_bit_identical_to_the_16_wide_path(K, L, M):
     assert relerr(plain, ref) <= 1e-13
     auto = host(K.transform_two_body(du, dC, dCt))
     assert np.array_equal(auto, plain)
+    # (sandwich_t2: the intermediate between the two passes in its natural layout / transposed)
     for knobs in (dict(sandwich=4), dict(sandwich=4, sandwich_mode=0), dict(sandwich=4, sandwich_mode=1),
-                  dict(sandwich=4, sandwich_mode=3), dict(sandwich=2), dict(sandwich=3)):
+                  dict(sandwich=4, sandwich_mode=3), dict(sandwich=4, sandwich_t2=0), dict(sandwich=4, sandwich_t2=1),
+                  dict(sandwich=1, sandwich_t2=0), dict(sandwich=1, sandwich_t2=1), dict(sandwich=2), dict(sandwich=3)):
         with K.tuning(**knobs):
             got = host(K.transform_two_body(du, dC, dCt))
             disp = K.last_dispatch()

@@ -1,6 +1,7 @@
 """Small-basis transform: the two fused 4-wide passes (qs_sandwich4.hip) against the previous path
 (fused (d, c) on the 16-wide instruction + two streaming products), same process, alternating runs:
 bit-equality of the results and time per transform.   python tools/sandwich_check.py [l ...]"""
+import os
 import sys
 
 import numpy as np
@@ -29,11 +30,15 @@ for l in ls:
     out = {}
     # 0 the 16-wide path, 1 automatic; forced wherever the kernel exists: 4 both passes, 5 (d, c) only, 6 (b, a) only
     MODES = (0, 1, 4, 5, 6) if len(ls) > 8 else (0, 1, 2, 3, 4, 10, 11, 13)
+    if os.environ.get("QS_MODES"):
+        MODES = tuple(int(x) for x in os.environ["QS_MODES"].split(","))
     for mode in MODES:
         if mode >= 10:
             K.tuning_set("sandwich", 1); K.tuning_set("sandwich_mode", mode - 10)
         else:
             K.tuning_reset(); K.tuning_set("sandwich", mode)
+        if os.environ.get("QS_T2"):
+            K.tuning_set("sandwich_t2", int(os.environ["QS_T2"]))
         res = torch.empty_like(u)
         K.transform_two_body(u, C, Ct, out=res)
         disp = K.last_dispatch()
