@@ -100,6 +100,8 @@ class _Checked:
                     assert all(obj.check_axis_lengths(block, obj.l))
             else:
                 assert all(obj.check_axis_lengths(value, obj.l))
+        if type(value) is torch.Tensor and is_device_module(obj.np):
+            value = wrap(value)         # (a plain tensor made while subclass dispatch was off)
         setattr(obj, self.slot, value)
 
 
@@ -311,13 +313,32 @@ class BasisSet:
         (:413-464).  Rectangular ``C`` changes ``l``."""
         if is_sharded_module(self.np):
             return sharded_basis.change_basis(self, C, C_tilde)
+        # (the host side of a small basis costs more than its kernels: inside, device arrays are handled as plain
+        # tensors -- no __torch_function__ round trip per tensor method -- and re-wrapped when they are stored)
+        with torch._C.DisableTorchFunctionSubclass():
+            return self._change_basis_on_device(C, C_tilde)
+
+    def _change_basis_on_device(self, C, C_tilde):
         np = self.np
         self.l = C.shape[1]                                     # :448
         d_C = _stage(C)
         d_Ct = kernels.default_bra(d_C) if C_tilde is None else _stage(C_tilde)
 
+        # real coefficients against complex matrices (the 2-D oscillator's spf, a complex h): the complex copies of
+        # C and C~ are made once per call, not once per transformed array
+        cast = {}
+
+        def coeffs(arr):
+            if d_C.is_complex() or not (isinstance(arr, torch.Tensor) and arr.is_complex()):
+                return d_C, d_Ct
+            if not cast:
+                cast["C"], cast["Ct"] = d_C.to(torch.complex128), d_Ct.to(torch.complex128)
+            return cast["C"], cast["Ct"]
+
         def one_body(arr):
-            return _deliver(kernels.transform_one_body(_stage(arr), d_C, d_Ct), np)
+            arr = _stage(arr)
+            c, ct = coeffs(arr)
+            return _deliver(kernels.transform_one_body(arr, c, ct), np)
 
         self.h = one_body(self.h)
         if self.s is not None:
@@ -363,8 +384,8 @@ class BasisSet:
         if self.momentum is not None:
             self.momentum = one_body(self.momentum)
         if self.spf is not None:
-            bra = self.transform_bra_spf(self.bra_spf, d_Ct, np)
-            ket = self.transform_spf(self.spf, d_C, np)
+            bra = self.transform_bra_spf(self.bra_spf, coeffs(_stage(self.bra_spf))[1], np)
+            ket = self.transform_spf(self.spf, coeffs(_stage(self.spf))[0], np)
             self.bra_spf = bra
             self.spf = ket
 

@@ -24,7 +24,24 @@ def dtype_code(dtype):
 
 
 def _stream():
-    return torch.cuda.current_stream().cuda_stream
+    """Raw handle of the current device's current stream (``torch.cuda.current_stream().cuda_stream`` without the
+    Python object around it: the wrappers below are on the path of every small-basis transform)."""
+    return torch._C._cuda_getCurrentRawStream(torch._C._cuda_getDevice())
+
+
+def _plain(fn):
+    """The wrapped function sees device arrays as plain tensors: every tensor method called on a ``torch.Tensor``
+    subclass (``DeviceArray``) otherwise goes through ``__torch_function__`` and re-wraps its result -- ~100 of those
+    per ``change_basis`` cost more than the kernels of a 55-orbital transform.  Results come back as plain tensors
+    (the callers wrap what they hand out)."""
+    import functools
+
+    @functools.wraps(fn)
+    def inner(*args, **kwargs):
+        with torch._C.DisableTorchFunctionSubclass():
+            return fn(*args, **kwargs)
+
+    return inner
 
 
 # Measurement hook (bench.py): when this is a list, every compute call appends the kernels it
@@ -49,7 +66,9 @@ def _dev(t, dtype=None):
         )
     if dtype is not None and t.dtype != dtype:
         t = t.to(dtype)
-    return t.resolve_conj().contiguous()
+    if t.is_conj():
+        t = t.resolve_conj()
+    return t if t.is_contiguous() else t.contiguous()
 
 
 class _on_device_of:
@@ -58,14 +77,22 @@ class _on_device_of:
     stream) and refuses operands that live on different devices."""
 
     def __init__(self, *tensors):
-        devs = {t.device for t in tensors if t is not None}
-        if len(devs) != 1:
-            raise ValueError(f"operands live on different devices: {sorted(str(d) for d in devs)}")
-        self.device = devs.pop()
+        dev = None
+        for t in tensors:
+            if t is None:
+                continue
+            if dev is None:
+                dev = t.device
+            elif t.device != dev:
+                devs = {x.device for x in tensors if x is not None}
+                raise ValueError(f"operands live on different devices: {sorted(str(d) for d in devs)}")
+        if dev is None:
+            raise ValueError("operands live on different devices: []")
+        self.device = dev
         self._guard = None
 
     def __enter__(self):
-        if self.device.index != torch.cuda.current_device():
+        if self.device.index != torch._C._cuda_getDevice():
             self._guard = torch.cuda.device(self.device)
             self._guard.__enter__()
         return self
@@ -102,6 +129,7 @@ def result_dtype(*tensors):
     return out
 
 
+@_plain
 def default_bra(C):
     """``C.conj().T`` materialised (basis_set.py:331-332, 338-339)."""
     if not isinstance(C, torch.Tensor):
@@ -138,6 +166,7 @@ class Workspace:
 workspace = Workspace()
 
 
+@_plain
 def gemm_raw(dt, A, B, out, m, n, k, lda, ldb, ldc, batch=1, sa=0, sb=0, sc=0,
              accumulate=False, a_off=0, b_off=0, c_off=0):
     """Thin call of ``qs_matmul`` on tensors already prepared by the caller
@@ -156,6 +185,7 @@ def gemm_raw(dt, A, B, out, m, n, k, lda, ldb, ldc, batch=1, sa=0, sb=0, sc=0,
     return out
 
 
+@_plain
 def matmul(A, B, out=None, accumulate=False):
     """Row-major ``A @ B`` for 2-D operands (or a shared 2-D ``A`` against a
     batch ``B`` of shape (batch, k, n)); ``accumulate`` adds into ``out``."""
@@ -185,6 +215,7 @@ def matmul(A, B, out=None, accumulate=False):
     return gemm_raw(dt, A, B, out, m, n, k, k, n, n, batch, 0, k * n, m * n, accumulate)
 
 
+@_plain
 def transform_two_body(u, C, C_tilde=None, out=None):
     """out[pqrs] = Ct[pa] Ct[qb] u[abcd] C[cr] C[ds]  (basis_set.py:336-350)."""
     lib = _lib.load()
@@ -217,6 +248,7 @@ def transform_two_body(u, C, C_tilde=None, out=None):
     return out
 
 
+@_plain
 def transform_two_body_(u, C, C_tilde=None):
     """The transform IN PLACE: ``u`` (L,L,L,L; float64 / complex128, contiguous, owning its storage) is overwritten
     and the result (M,M,M,M), M <= L, is returned as a view of the start of its storage.  One L^3 M spare buffer
@@ -307,6 +339,7 @@ class TransformPlan:
         return self.out
 
 
+@_plain
 def transform_two_body_partial(u_slab, C, C_tilde=None, out=None):
     """Contractions over d, c, b of a leading-index slab:
     v[a,q,r,s] = Ct[qb] u[a,b,c,d] C[cr] C[ds] for the rows of the slab."""
@@ -341,6 +374,7 @@ def transform_two_body_partial(u_slab, C, C_tilde=None, out=None):
     return out
 
 
+@_plain
 def transform_one_body(h, C, C_tilde=None):
     """``Ct @ (h @ C)`` for one (L,L) matrix or a stack (n,L,L)
     (basis_set.py:329-334)."""
@@ -371,6 +405,7 @@ def transform_one_body(h, C, C_tilde=None):
     return out[0] if single else out.reshape(*h.shape[:-2], M, M)
 
 
+@_plain
 def antisymmetrize(u, out=None):
     """``u - u.transpose(0,1,3,2)`` (basis_set.py:776-778); pass ``out=u`` for
     the in-place form."""
@@ -399,6 +434,7 @@ def antisymmetrize(u, out=None):
     return out
 
 
+@_plain
 def spin_expand_two_body(u, antisymmetrize=False, out_dtype=None, p_lo=0, p_hi=None, out=None):
     """Spin doubling of (l,l,l,l) -> rows [2 p_lo, 2 p_hi) of (2l,2l,2l,2l)
     (basis_set.py:772-774), optionally fused with the anti-symmetrisation
@@ -436,6 +472,7 @@ def spin_expand_two_body(u, antisymmetrize=False, out_dtype=None, p_lo=0, p_hi=N
     return out
 
 
+@_plain
 def spin_expand_two_body_block(u_block, antisymmetrize=False, out_dtype=None, out=None):
     """Spin doubling of a block ``u[p0:p0+np, q0:q0+nq, :, :]`` of shape (np, nq, l, l) ->
     (2 np, 2 nq, 2l, 2l): what a rank of a sharded tensor holds, whichever of the two leading
@@ -465,6 +502,7 @@ def spin_expand_two_body_block(u_block, antisymmetrize=False, out_dtype=None, ou
     return out
 
 
+@_plain
 def add_spin_one_body(h, out_dtype=None):
     """``kron(h, I2)`` for (l,l) or a stack (n,l,l) (basis_set.py:768-770)."""
     lib = _lib.load()
@@ -486,6 +524,7 @@ def add_spin_one_body(h, out_dtype=None):
     return out
 
 
+@_plain
 def spin_squared_two_body(S, antisymmetrize=False, p_lo=0, p_hi=None):
     """Two-body S^2 from the stacked (3,n,n) spin matrices
     (basis_set.py:745-747)."""
@@ -506,6 +545,7 @@ def spin_squared_two_body(S, antisymmetrize=False, p_lo=0, p_hi=None):
     return out
 
 
+@_plain
 def two_body_from_grid(K, C, C_tilde=None, antisymmetrize=False):
     """Two-body elements of an interaction that is DIAGONAL on a grid / DVR basis,
 
@@ -534,6 +574,7 @@ def two_body_from_grid(K, C, C_tilde=None, antisymmetrize=False):
     return out
 
 
+@_plain
 def antisymmetrize_(u):
     """In-place form of ``antisymmetrize``."""
     return antisymmetrize(u, out=u)
