@@ -200,6 +200,7 @@ int qs_tuning_set(const char* key, int64_t value) {
     if (!strcmp(key, "sandwich")) { g_tune.sandwich = (int)value; return QS_OK; }
     if (!strcmp(key, "sandwich_mode")) { g_tune.sandwich_mode = (int)value; return QS_OK; }
     if (!strcmp(key, "sandwich_t2")) { g_tune.sandwich_t2 = (int)value; return QS_OK; }
+    if (!strcmp(key, "sandwich_v2")) { g_tune.sandwich_v2 = (int)value; return QS_OK; }
     return QS_ERR_BAD_EXTENT;
 }
 

@@ -42,6 +42,7 @@
 #include <type_traits>
 
 #include "qs_common.h"
+#include "qs_sandwich4.h"
 
 // Development builds only (never defined in the shipped library): bit mask of parts to leave out, to find
 // what bounds the kernel.  1 fetch, 2 stores, 16 all MFMAs, 32 return after the tables are built, 64 return at once,
@@ -93,20 +94,6 @@ __device__ __forceinline__ double mfma4(double a, double b, double c) {
 }
 
 }  // namespace
-
-struct S4Args {
-    const double* in;
-    double* out;
-    const double* R;      // R[k][j]  = R[k * r_sk + j * r_sj],   L x M
-    const double* Lm;     // Lm[p][a] = Lm[p * l_sp + a * l_sa],  M x L
-    int64_t r_sk, r_sj, l_sp, l_sa;
-    int64_t in_item, in_row, in_col;       // element strides of In_t[i][k]: in_col == 1 (a slab) or in_item == 1 (a column)
-    int64_t out_item, out_row, out_col;    // element strides of Out_t[p][j]
-    int L, M;
-    unsigned nitems, nquads;
-    int mode;      // bit 0: the four waves take four ADJACENT item quads and the same chunk (else: one quad, four chunks);
-                   // bit 1: with bit 0, a workgroup barrier per step keeps the four waves' fetches together in L1
-};
 
 // N4 = ceil(L / 4) = ceil(M / 4)
 template <int N4>
@@ -562,15 +549,22 @@ int sandwich4_try(int dtype, const void* in, void* out, const void* R, int64_t r
     if (n4 != (int)cdiv(M, 4)) return 1;                 // (near-)square products only
     if (nitems < 1024 || nitems >= (int64_t(1) << 31)) return 1;    // enough item quads to occupy the chip
     if (in_col != 1 && in_item != 1) return 1;           // the fetch takes 16 contiguous bytes per lane along k or the item
-    // Where this kernel measures faster than the 16-wide path (same-box sweep over l = 21 ... 64,
-    // profiles/r02_small_basis_sweep.txt; g_tune.sandwich >= 4 overrides for tuning runs):
+    // Slabs in: the balanced form with a cooperative fetch (qs_sandwich4b.hip) where it exists and measured faster
+    // (same-box sweep, profiles/r02_small_basis_sweep.txt: 2-7 % for ceil(l/4) in {10, 14, 16} except l = 40 and 56,
+    // and ceil(l/4) = 12 -- where the four-chunk split of this file leaves a SIMD idle -- wins its first pass back).
+    const bool v2 = in_col == 1 && (g_tune.sandwich_v2 > 0 ||
+                                    (g_tune.sandwich_v2 < 0 && (n4 == 10 || n4 == 12 || n4 == 14 || n4 == 16) &&
+                                     !(L % 4 == 0 && (n4 == 10 || n4 == 14))));
+    // Where these kernels measure faster than the 16-wide path (same sweep; g_tune.sandwich >= 4 overrides for tuning
+    // runs):
     //   * ceil(l/4) = 15 spills registers (two chunk bodies for the parity of the ring x 15 x 4 accumulators) and loses;
     //   * below ceil(l/4) = 9 the transform is launch-bound either way;
-    //   * slabs in, slabs out (the (d, c) pass with T2 in its natural layout) lose for ceil(l/4) in {11, 12};
+    //   * slabs in, slabs out (the (d, c) pass with T2 in its natural layout) lose for ceil(l/4) = 11, and for 12 unless
+    //     the balanced form runs;
     //   * slabs in, interleaved items out (either pass when T2 is stored transposed) lose for ceil(l/4) = 12.
     if (g_tune.sandwich < 4) {
         if (n4 == 15 || n4 < 9) return 1;
-        if (in_item != 1 && out_item != 1 && (n4 == 11 || n4 == 12)) return 1;
+        if (in_item != 1 && out_item != 1 && (n4 == 11 || (n4 == 12 && !v2))) return 1;
         if (in_item != 1 && out_item == 1 && n4 == 12) return 1;
     }
     // every byte offset inside an item quad stays below 2^31
@@ -589,6 +583,10 @@ int sandwich4_try(int dtype, const void* in, void* out, const void* R, int64_t r
     // items 8 bytes apart (the (b, a) pass): four adjacent quads per workgroup make whole lines; contiguous items
     // (the (d, c) pass): a workgroup per quad keeps its four fetch streams on the same lines
     g.mode = g_tune.sandwich_mode >= 0 ? g_tune.sandwich_mode : (in_item == 1 ? 3 : 0);
+    if (v2) {
+        const int rc = sandwich4b_launch(g, n4, stream);
+        if (rc != 1) return rc;
+    }
     switch (n4) {
 #ifdef QS_S4_ONLY          // development builds: one instantiation compiles in seconds
         case QS_S4_ONLY: return launch_sandwich4<QS_S4_ONLY>(g, stream);

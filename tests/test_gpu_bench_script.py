@@ -48,7 +48,7 @@ def test_transform_line_has_the_contract_fields():
 def test_transform_line_names_the_small_basis_kernels():
     d = run_bench("--orbitals", "55", "--no-cpu-baseline", "--no-probes")
     # config 2 runs as two fused passes on the 4-wide matrix instruction; the line names that kernel
-    assert d["roofline"]["kernel"] == "qs::sandwich4_kernel<14>" and d["roofline"]["launches_per_step"] == 2
+    assert d["roofline"]["kernel"] == "qs::sandwich4b_kernel<14>" and d["roofline"]["launches_per_step"] == 2
     assert d["parity"]["ok"] is True
 
 

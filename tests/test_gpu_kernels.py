@@ -547,6 +547,20 @@ def test_fused_dc_pass_keeps_non_finite_values_in_their_slabs(K):
 # ------------------------- both halves of a small-basis transform on the 4-wide instruction (qs_sandwich4.hip)
 
 
+def _sandwich_launches(dispatch, n4):
+    """Number of launches in a dispatch record that are one of the two 4-wide kernels for ceil(l/4) = n4 (0 if anything
+    else ran)."""
+    import re
+
+    total = 0
+    for item in dispatch.split(";"):
+        m = re.fullmatch(rf"qs::sandwich4b?_kernel<{n4}>(?: x(\d+))?", item)
+        if not m:
+            return 0
+        total += int(m.group(1) or 1)
+    return total
+
+
 @pytest.mark.parametrize("L,M", [(32, 32), (33, 33), (36, 34), (40, 40), (41, 44), (47, 48), (50, 49), (53, 55),
                                  (55, 55), (55, 53), (56, 56), (58, 60), (61, 64), (64, 64)])
 def test_sandwich_passes_bit_identical_to_the_16_wide_path(K, L, M):
@@ -568,8 +582,11 @@ def test_sandwich_passes_bit_identical_to_the_16_wide_path(K, L, M):
     auto = host(K.transform_two_body(du, dC, dCt))
     assert np.array_equal(auto, plain)
     # (sandwich_t2: the intermediate between the two passes in its natural layout / transposed)
+    # sandwich_v2: the balanced kernel with a cooperative fetch (qs_sandwich4b.hip) never / wherever it exists)
     for knobs in (dict(sandwich=4), dict(sandwich=4, sandwich_mode=0), dict(sandwich=4, sandwich_mode=1),
                   dict(sandwich=4, sandwich_mode=3), dict(sandwich=4, sandwich_t2=0), dict(sandwich=4, sandwich_t2=1),
+                  dict(sandwich=4, sandwich_v2=0), dict(sandwich=4, sandwich_v2=1, sandwich_t2=1),
+                  dict(sandwich=4, sandwich_v2=1, sandwich_t2=0), dict(sandwich=1, sandwich_v2=1),
                   dict(sandwich=1, sandwich_t2=0), dict(sandwich=1, sandwich_t2=1), dict(sandwich=2), dict(sandwich=3)):
         with K.tuning(**knobs):
             got = host(K.transform_two_body(du, dC, dCt))
@@ -578,7 +595,7 @@ def test_sandwich_passes_bit_identical_to_the_16_wide_path(K, L, M):
         assert np.array_equal(got, plain), knobs
         assert np.array_equal(part, plain_part), knobs
         if knobs.get("sandwich") == 4:
-            assert disp == f"qs::sandwich4_kernel<{-(-L // 4)}> x2", disp
+            assert _sandwich_launches(disp, -(-L // 4)) == 2, disp
 
 
 def test_sandwich_is_the_automatic_choice_for_config_2(K):
@@ -587,7 +604,7 @@ def test_sandwich_is_the_automatic_choice_for_config_2(K):
     u = torch.rand(55, 55, 55, 55, dtype=torch.float64, device="cuda:0", generator=g)
     C, _ = torch.linalg.qr(torch.randn(55, 55, dtype=torch.float64, device="cuda:0", generator=g))
     out = K.transform_two_body(u, C.contiguous())
-    assert K.last_dispatch() == "qs::sandwich4_kernel<14> x2"
+    assert K.last_dispatch() == "qs::sandwich4b_kernel<14> x2"
     ref = orc.transform_two_body(host(u), host(C))
     assert relerr(host(out), ref) <= 1e-13
 
@@ -632,7 +649,7 @@ def test_sandwich_reads_nothing_outside_the_tensor(K, L):
     out = obig[pad:pad + n].view(L, L, L, L)
     with K.tuning(sandwich=4):
         K.transform_two_body(u, C, Ct, out=out)
-        assert K.last_dispatch() == f"qs::sandwich4_kernel<{-(-L // 4)}> x2"
+        assert _sandwich_launches(K.last_dispatch(), -(-L // 4)) == 2
     assert torch.equal(out, ref)
     assert torch.isnan(obig[:pad]).all() and torch.isnan(obig[pad + n:]).all()      # nothing written outside either
     assert torch.isnan(big[:pad]).all() and torch.isnan(big[pad + n:]).all()

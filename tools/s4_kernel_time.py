@@ -31,6 +31,8 @@ u = torch.rand((l,) * 4, dtype=torch.float64, device="cuda", generator=g) - 0.5
 C, _ = torch.linalg.qr(torch.randn(l, l, dtype=torch.float64, device="cuda", generator=g))
 C = C.contiguous(); Ct = C.t().contiguous()
 out = torch.empty_like(u)
+if os.environ.get("QS_V2ENV"):
+    K.tuning_set("sandwich_v2", int(os.environ["QS_V2ENV"]))
 for _ in range(10):
     K.transform_two_body(u, C, Ct, out=out)
 torch.cuda.synchronize()

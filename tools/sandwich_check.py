@@ -37,6 +37,8 @@ for l in ls:
             K.tuning_set("sandwich", 1); K.tuning_set("sandwich_mode", mode - 10)
         else:
             K.tuning_reset(); K.tuning_set("sandwich", mode)
+        if os.environ.get("QS_V2"):
+            K.tuning_set("sandwich_v2", int(os.environ["QS_V2"]))
         if os.environ.get("QS_T2"):
             K.tuning_set("sandwich_t2", int(os.environ["QS_T2"]))
         res = torch.empty_like(u)
