@@ -263,7 +263,10 @@ __global__ __launch_bounds__(256, 1) void sandwich4b_kernel(const S4Args g) {
         unroll_b<0, N4>([&](auto KA) __attribute__((always_inline)) {
             constexpr int ka = decltype(KA)::value, st = ka & 1;
             QS_S4B_STAMP(ka)
-            if constexpr (!(ka & 1)) lds_barrier();
+            // An even step carries the barrier: behind its first two k quads, and all of the step's LDS traffic behind
+            // that -- the wait for this wave's own LDS instructions in front of the barrier then finds them done (at
+            // the very start of the step the last ring reads of the step before are still on their way).
+            constexpr int SH = (ka & 1) ? 0 : 2;
             if constexpr (E != 0) {
                 if ((ka & 1) == mpar) {        // this wave's row quad of the shared group: one chain, a block of its own
                     unroll_b<0, N4>([&](auto KS) __attribute__((always_inline)) {
@@ -273,24 +276,34 @@ __global__ __launch_bounds__(256, 1) void sandwich4b_kernel(const S4Args g) {
                 }
                 __builtin_amdgcn_sched_barrier(0);
             }
+            auto read_next = [&](auto F_) __attribute__((always_inline)) {      // fragment F of row quad ka + 1
+                if constexpr (ka + 1 >= N4) read_frag(rd_nx, std::integral_constant<int, ka + 1 - N4>{}, F_);
+                else read_frag(rd_in, std::integral_constant<int, ka + 1>{}, F_);
+            };
             unroll_b<0, N4>([&](auto KS) __attribute__((always_inline)) {
                 constexpr int ks = decltype(KS)::value;
                 unroll_b<0, Q>([&](auto J) __attribute__((always_inline)) {
                     constexpr int j = decltype(J)::value;
-                    Y[ka][j] = mfma4b(ring[st][ks], bf[ks][j], ks == 0 ? 0.0 : Y[ka][j]);
-                    if constexpr (j == 0) {
-                        if constexpr (ka + 1 >= N4) read_frag(rd_nx, std::integral_constant<int, ka + 1 - N4>{}, KS);
-                        else read_frag(rd_in, std::integral_constant<int, ka + 1>{}, KS);
+                    if constexpr (SH != 0 && ks == SH && j == 0) {
+                        lds_barrier();
+                        __builtin_amdgcn_sched_barrier(0);
                     }
-                    if constexpr (j == 1) {
-                        // k quads 0 .. 2 PW - 1: the writes of row quad ka + 3; the next PW: the loads of row quad ka + 5
-                        if constexpr (ks < 2 * PW) {
-                            using I_ = std::integral_constant<int, ks / 2>;
-                            using H_ = std::integral_constant<int, ks % 2>;
+                    Y[ka][j] = mfma4b(ring[st][ks], bf[ks][j], ks == 0 ? 0.0 : Y[ka][j]);
+                    if constexpr (j == 0 && ks >= SH) {
+                        read_next(std::integral_constant<int, ks - SH>{});
+                        // (the last SH fragments ride with the last k quads' reads: two LDS reads behind one MFMA are free)
+                        if constexpr (ks >= N4 - SH) read_next(std::integral_constant<int, ks>{});
+                    }
+                    if constexpr (j == 1 && ks >= SH) {
+                        // the writes of row quad ka + 3 (2 PW k quads), then the loads of row quad ka + 5 (PW k quads)
+                        constexpr int t = ks - SH;
+                        if constexpr (t < 2 * PW) {
+                            using I_ = std::integral_constant<int, t / 2>;
+                            using H_ = std::integral_constant<int, t % 2>;
                             if constexpr (ka + 3 >= N4) write_elem(w_nx, std::integral_constant<int, ka + 3 - N4>{}, I_{}, H_{});
                             else write_elem(w_in, std::integral_constant<int, ka + 3>{}, I_{}, H_{});
-                        } else if constexpr (ks < 3 * PW) {
-                            using I_ = std::integral_constant<int, ks - 2 * PW>;
+                        } else if constexpr (t < 3 * PW) {
+                            using I_ = std::integral_constant<int, t - 2 * PW>;
                             if constexpr (ka + 5 >= N4) load_pair(rs_nx, v_nx, std::integral_constant<int, ka + 5 - N4>{}, I_{});
                             else load_pair(rs_in, v_in, std::integral_constant<int, ka + 5>{}, I_{});
                         } else if constexpr (ka == N4 - 1 && Q == 2) {
