@@ -210,6 +210,26 @@ __global__ __launch_bounds__(256, 1) void sandwich4b_kernel(const S4Args g) {
         ring[r & 1][ks] = transit[(r & 1) * SET + ks * 64 + rd[ks & 1][(r >> 1) & 1]];
     };
 
+    // The fragments of R for this wave's groups: the same for every item quad (a wave keeps its groups), read once
+    // after the tables are built.
+    const int jg0 = Q * wave;                 // first own group (wave-uniform)
+    const int jx = 4 * Q + pair;              // the pair's shared group (E == 2)
+    double bf[N4][Q];
+    double bx[E ? N4 : 1];
+    auto load_r_fragments = [&]() __attribute__((always_inline)) {
+        unroll_b<0, N4>([&](auto KS) __attribute__((always_inline)) {
+            unroll_b<0, Q>([&](auto J) __attribute__((always_inline)) {
+                bf[decltype(KS)::value][decltype(J)::value] =
+                    rtab[(decltype(KS)::value * N4 + jg0 + decltype(J)::value) * 16 + e_lane];
+            });
+        });
+        if constexpr (E != 0) {
+            unroll_b<0, N4>([&](auto KS) __attribute__((always_inline)) {
+                bx[decltype(KS)::value] = rtab[(decltype(KS)::value * N4 + jx) * 16 + e_lane];
+            });
+        }
+    };
+
     // One item quad, in two phases (qs_sandwich4.hip): Y[ka] = In[ka] . R[:, own groups], then Out[pg] = sum_ka
     // Lm[pg][ka] . Y[ka].  Step ka of phase 1: (a barrier before every even one;) behind the MFMAs of row quad ka the
     // fragments of row quad ka + 1 are READ from the transit buffer, this wave's pairs of row quad ka + 3 are WRITTEN
@@ -219,21 +239,6 @@ __global__ __launch_bounds__(256, 1) void sandwich4b_kernel(const S4Args g) {
     auto quad_pass = [&](auto rs_in, auto rs_out, const unsigned (&v_out)[4], auto rs_nx, const unsigned (&v_nx)[PW][2],
                          const unsigned (&w_nx)[PW][2][2], const unsigned (&rd_nx)[2][2], const unsigned (&v_in)[PW][2],
                          const unsigned (&w_in)[PW][2][2], const unsigned (&rd_in)[2][2]) __attribute__((always_inline)) {
-        const int jg0 = Q * wave;                 // first own group (wave-uniform)
-        const int jx = 4 * Q + pair;              // the pair's shared group (E == 2)
-        double bf[N4][Q];
-        unroll_b<0, N4>([&](auto KS) __attribute__((always_inline)) {
-            unroll_b<0, Q>([&](auto J) __attribute__((always_inline)) {
-                bf[decltype(KS)::value][decltype(J)::value] =
-                    rtab[(decltype(KS)::value * N4 + jg0 + decltype(J)::value) * 16 + e_lane];
-            });
-        });
-        double bx[E ? N4 : 1];
-        if constexpr (E != 0) {
-            unroll_b<0, N4>([&](auto KS) __attribute__((always_inline)) {
-                bx[decltype(KS)::value] = rtab[(decltype(KS)::value * N4 + jx) * 16 + e_lane];
-            });
-        }
         double Y[N4][Q];
         double Yh[E ? N4 / 2 : 1];       // this wave's half of Y of the shared group: row quads 2 i + mpar
         double lf[2][N4];                // fragments of Lm for row quads pg (stage pg & 1) and pg + 1
@@ -422,6 +427,7 @@ __global__ __launch_bounds__(256, 1) void sandwich4b_kernel(const S4Args g) {
         }
     }
     __syncthreads();
+    load_r_fragments();
     // row quads 0, 1, 2 into the transit buffer, 3 and 4 into the registers the first two leave, row quad 0 into the ring
     unroll_b<0, 2>([&](auto R_) __attribute__((always_inline)) {
         unroll_b<0, PW>([&](auto I_) __attribute__((always_inline)) {
