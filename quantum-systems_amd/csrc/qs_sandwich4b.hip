@@ -295,13 +295,13 @@ __global__ __launch_bounds__(256, 1) void sandwich4b_kernel(const S4Args g) {
                     }
                     Y[ka][j] = mfma4b(ring[st][ks], bf[ks][j], ks == 0 ? 0.0 : Y[ka][j]);
                     if constexpr (j == 0 && ks >= SH) {
-                        read_next(std::integral_constant<int, ks - SH>{});
+                        read_next(std::integral_constant<int, (ks >= SH ? ks - SH : 0)>{});
                         // (the last SH fragments ride with the last k quads' reads: two LDS reads behind one MFMA are free)
                         if constexpr (ks >= N4 - SH) read_next(std::integral_constant<int, ks>{});
                     }
                     if constexpr (j == 1 && ks >= SH) {
                         // the writes of row quad ka + 3 (2 PW k quads), then the loads of row quad ka + 5 (PW k quads)
-                        constexpr int t = ks - SH;
+                        constexpr int t = ks >= SH ? ks - SH : 0;
                         if constexpr (t < 2 * PW) {
                             using I_ = std::integral_constant<int, t / 2>;
                             using H_ = std::integral_constant<int, t % 2>;
