@@ -21,6 +21,16 @@
 #include "qs_common.h"
 #include "qs_sandwich4.h"
 
+// development: -DQS_S4B_EXPERIMENT=1 nobody runs the shared group's chains (every step branches around them),
+// =2 the chains are compiled out (timing experiments; results are wrong)
+#ifndef QS_S4B_EXPERIMENT
+#define QS_S4B_OWNER(par) ((par) == mpar)
+#elif QS_S4B_EXPERIMENT == 1
+#define QS_S4B_OWNER(par) (mpar == 2 + (par))
+#else
+#define QS_S4B_OWNER(par) false
+#endif
+
 namespace qs {
 
 namespace {
@@ -273,7 +283,7 @@ __global__ __launch_bounds__(256, 1) void sandwich4b_kernel(const S4Args g) {
             // the very start of the step the last ring reads of the step before are still on their way).
             constexpr int SH = (ka & 1) ? 0 : 2;
             if constexpr (E != 0) {
-                if ((ka & 1) == mpar) {        // this wave's row quad of the shared group: one chain, a block of its own
+                if (QS_S4B_OWNER((ka & 1))) {        // this wave's row quad of the shared group: one chain, a block of its own
                     unroll_b<0, N4>([&](auto KS) __attribute__((always_inline)) {
                         constexpr int ks = decltype(KS)::value;
                         Yh[ka / 2] = mfma4b(ring[st][ks], bx[ks], ks == 0 ? 0.0 : Yh[ka / 2]);
@@ -344,7 +354,7 @@ __global__ __launch_bounds__(256, 1) void sandwich4b_kernel(const S4Args g) {
             QS_S4B_STAMP(64 + pg)
             const unsigned s_prev = opaque((pg ? pg - 1 : 0) * pg_step);
             if constexpr (E != 0) {
-                if ((pg & 1) == mpar) {
+                if (QS_S4B_OWNER((pg & 1))) {
                     unroll_b<0, N4>([&](auto KA) __attribute__((always_inline)) {
                         constexpr int ka = decltype(KA)::value;
                         ovx[b] = mfma4b(lf[b][ka], Yx[ka], ka == 0 ? 0.0 : ovx[b]);
