@@ -265,16 +265,20 @@ int qs_transform_two_body(int dtype, const void* u, const void* C, const void* C
         const int64_t n4 = cdiv(L, 4);
         const bool second_ok = dtype == QS_F64 && L <= 64 && M <= 64 && n4 == cdiv(M, 4) && MM >= 1024 &&
                                (4 * n4) * L * MM * 2 * 8 < (int64_t(1) << 31) &&
-                               (g_tune.sandwich >= 4 ? n4 >= 6 : (n4 >= 9 && n4 != 15));
+                               (g_tune.sandwich >= 4 ? n4 >= 6 : n4 >= 9) &&
+                               // (15: both passes on slabs through the balanced kernel's instantiation for 16, or not at all)
+                               (n4 != 15 || (g_tune.sandwich_v2 != 0 && g_tune.sandwich_t2 != 0 && g_tune.sandwich != 3 &&
+                                             g_tune.sandwich != 6));
         if (second_ok) {
             void* T1s = (M < L) ? at(WA, wa, es) : out;     // scratch of the unfused fall-back of the first pass
             int rc2 = 1;
             // T2 transposed, (r, s, a, b): the second pass then fetches slabs like the first (64-byte runs, the four
             // waves of a workgroup on the same lines) instead of columns (32-byte runs), and the first one stores the
             // way the second does.  Same-box sweep (profiles/r02_small_basis_sweep.txt): 4-10 % faster for
-            // ceil(l/4) in {10, 13, 14, 16}, faster than the second pass alone for 11, slower for 9 and 12.
+            // ceil(l/4) in {10, 13, 14, 16}, faster than the second pass alone for 11, slower for 9 and 12; 15 has
+            // slab passes only (the balanced kernel's instantiation for 16).
             const bool want_t2 = g_tune.sandwich_t2 >= 0 ? g_tune.sandwich_t2 != 0
-                                                         : (n4 == 10 || n4 == 11 || n4 == 13 || n4 == 14 || n4 == 16);
+                                                         : (n4 == 10 || n4 == 11 || n4 >= 13);
             bool t2_transposed = false;
             if (g_tune.sandwich != 3 && g_tune.sandwich != 6) {
                 if (want_t2)

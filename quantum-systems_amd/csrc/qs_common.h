@@ -134,7 +134,8 @@ struct Tuning {
     int gemm_stream = 1;         // 0 disables the small-coefficient streaming product, 2 = never split rows over two waves
     int slab_pair = 1;           // 0 disables the fused (d, c) pass, 2 = one wave per slab always
     int sandwich_t2 = -1;        // the intermediate of the two fused passes stored transposed, (r, s, a, b): -1 automatic, 0 never, 1 always
-    int sandwich_v2 = -1;        // the balanced small-basis kernel with a cooperative fetch (qs_sandwich4b.hip): -1 automatic, 0 never, 1 wherever it exists
+    int sandwich_v2 = -1;        // the balanced small-basis kernel with a cooperative fetch (qs_sandwich4b.hip): -1 automatic, 0 never, 1 wherever it exists,
+                                 // 2 also every odd ceil(l/4) on the instantiation for the next even one
     int sandwich_mode = -1;      // work split of the fused passes: -1 automatic, 0 one item quad per workgroup, 1 four adjacent quads, 3 + step barrier
     int sandwich = 1;            // 4-wide fused passes of a small-basis transform: 0 off, 1 both (d, c) and (b, a), 2 (d, c) only, 3 (b, a) only;
                                  // tuning runs, wherever the kernel exists (not only where it measured faster): 4 both, 5 (d, c) only, 6 (b, a) only

@@ -21,7 +21,8 @@ struct S4Args {
                    // bit 1: with bit 0, a workgroup barrier per step keeps the four waves' fetches together in L1
 };
 
-// The balanced form with a cooperative fetch (qs_sandwich4b.hip): slabs in (in_col == 1), ceil(L/4) in {10, 12, 14, 16}.
+// The balanced form with a cooperative fetch (qs_sandwich4b.hip): slabs in (in_col == 1), instantiations for n4 in
+// {10, 12, 14, 16}, each for 4 (n4 - 2) < L, M <= 4 n4.
 // QS_OK / error after launching, 1 = no such instantiation.
 int sandwich4b_launch(const S4Args& g, int n4, hipStream_t stream);
 

@@ -552,18 +552,27 @@ int sandwich4_try(int dtype, const void* in, void* out, const void* R, int64_t r
     // Slabs in: the balanced form with a cooperative fetch (qs_sandwich4b.hip) where it exists and measured faster
     // (same-box sweep, profiles/r02_small_basis_sweep.txt: 2-7 % for ceil(l/4) in {10, 14, 16} except l = 40 and 56,
     // and ceil(l/4) = 12 -- where the four-chunk split of this file leaves a SIMD idle -- wins its first pass back).
-    const bool v2 = in_col == 1 && (g_tune.sandwich_v2 > 0 ||
-                                    (g_tune.sandwich_v2 < 0 && (n4 == 10 || n4 == 12 || n4 == 14 || n4 == 16) &&
-                                     !(L % 4 == 0 && (n4 == 10 || n4 == 14))));
+    // Its instantiation for N4 also takes ceil(l/4) = N4 - 1 (the last two quads may be incomplete or empty): 15, which
+    // spills here, runs on the one for 16 (l = 57 ... 60: 150-185 -> 130-140 us), 11 on the one for 12 (44 -> 38 us);
+    // 9 and 13 measured slower that way (g_tune.sandwich_v2 == 2: every odd one on the next even one).
+    int n4k = n4;
+    bool v2 = in_col == 1 && (g_tune.sandwich_v2 > 0 ||
+                              (g_tune.sandwich_v2 < 0 && (n4 == 10 || n4 == 12 || n4 == 14 || n4 == 16) &&
+                               !(L % 4 == 0 && (n4 == 10 || n4 == 14))));
+    if (in_col == 1 && (n4 & 1) && n4 >= 9 && (g_tune.sandwich_v2 == 2 || (g_tune.sandwich_v2 < 0 && (n4 == 11 || n4 == 15)))) {
+        v2 = true;
+        n4k = n4 + 1;
+    }
     // Where these kernels measure faster than the 16-wide path (same sweep; g_tune.sandwich >= 4 overrides for tuning
     // runs):
-    //   * ceil(l/4) = 15 spills registers (two chunk bodies for the parity of the ring x 15 x 4 accumulators) and loses;
+    //   * ceil(l/4) = 15 spills registers here (two chunk bodies for the parity of the ring x 15 x 4 accumulators):
+    //     only the balanced form takes it;
     //   * below ceil(l/4) = 9 the transform is launch-bound either way;
     //   * slabs in, slabs out (the (d, c) pass with T2 in its natural layout) lose for ceil(l/4) = 11, and for 12 unless
     //     the balanced form runs;
     //   * slabs in, interleaved items out (either pass when T2 is stored transposed) lose for ceil(l/4) = 12.
     if (g_tune.sandwich < 4) {
-        if (n4 == 15 || n4 < 9) return 1;
+        if (n4 < 9 || (n4 == 15 && !v2)) return 1;
         if (in_item != 1 && out_item != 1 && (n4 == 11 || (n4 == 12 && !v2))) return 1;
         if (in_item != 1 && out_item == 1 && n4 == 12) return 1;
     }
@@ -584,7 +593,7 @@ int sandwich4_try(int dtype, const void* in, void* out, const void* R, int64_t r
     // (the (d, c) pass): a workgroup per quad keeps its four fetch streams on the same lines
     g.mode = g_tune.sandwich_mode >= 0 ? g_tune.sandwich_mode : (in_item == 1 ? 3 : 0);
     if (v2) {
-        const int rc = sandwich4b_launch(g, n4, stream);
+        const int rc = sandwich4b_launch(g, n4k, stream);
         if (rc != 1) return rc;
     }
     switch (n4) {

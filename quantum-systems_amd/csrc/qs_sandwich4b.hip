@@ -79,7 +79,8 @@ __device__ __forceinline__ void lds_barrier() {
 
 }  // namespace
 
-// N4 = ceil(L / 4) = ceil(M / 4), even, N4 % 4 in {0, 2}
+// 4 (N4 - 2) < L, M <= 4 N4 (the last TWO row / column quads may be incomplete or empty: ceil(l/4) = N4 - 1 runs here
+// too); N4 even, N4 % 4 in {0, 2}
 template <int N4>
 __global__ __launch_bounds__(256, 1) void sandwich4b_kernel(const S4Args g) {
     constexpr int Q = N4 / 4;                 // column groups of a wave's own
@@ -102,7 +103,6 @@ __global__ __launch_bounds__(256, 1) void sandwich4b_kernel(const S4Args g) {
     const int pair = wave >> 1, mpar = wave & 1;
     const int x = lane & 3, y = (lane >> 2) & 3, z = lane >> 4;
     const int e_lane = z * 4 + x;
-    const int rl = L & 3, rm = M & 3;      // valid rows / columns of the last quad (0 = all four)
     unsigned tr_n = 0;
     (void)tr_n;
 #ifdef QS_S4_TRACE
@@ -136,18 +136,17 @@ __global__ __launch_bounds__(256, 1) void sandwich4b_kernel(const S4Args g) {
     };
     const unsigned rd_even = slot_pos(x, y, z, 0), rd_odd = slot_pos(x, y, z, 1);
     // Per item quad and per pair i of this wave (pair number wave + 4 i): the lane offset of its fetch for interior
-    // row quads and for the last one (v[i][0 / 1]) and where its two elements go in the transit buffer (w[i][0 / 1][c],
+    // row quads and for the last two (v[i][0 / 1 / 2]) and where its two elements go in the transit buffer (w[i][0 / 1][c],
     // in doubles; c = bit 1 of the row quad).  A lane whose row / k / item does not exist is parked (the hardware
     // returns zeros); so is every lane of a pair that does not exist.  The last k of an odd L: see qs_sandwich4.hip (the
     // lane fetches 8 bytes earlier, its first half goes to words nobody reads, the missing element's place stays zero).
     // Transit set of row quad r of an item quad: 2 (((r >> 1) & 1) ^ ph) + (r & 1), ph = the parity of the item quad's
     // first pair of row quads in the workgroup's sequence (N4 / 2 may be odd); the (r & 1) part is an immediate, the
     // rest sits in the address registers: w, and rd[parity of the k quad][c] for the reads.
-    auto in_offsets = [&](unsigned quad, bool live, unsigned ph, unsigned (&v)[PW][2], unsigned (&w)[PW][2][2],
+    auto in_offsets = [&](unsigned quad, bool live, unsigned ph, unsigned (&v)[PW][3], unsigned (&w)[PW][2][2],
                           unsigned (&rd)[2][2]) __attribute__((always_inline)) {
         const int64_t el = f_row * g.in_row + f_item * g.in_item + (4 * f_par + f_k0);
         const unsigned base = (unsigned)(el * 8) + 8;
-        const bool row_ok = rl == 0 || f_row < rl;
         const bool item_ok = live && quad * 4 + f_item < g.nitems;
         const unsigned p0 = f_par * 64 + slot_pos(f_row, f_item, f_k0, f_par);
         const unsigned p1 = f_par * 64 + slot_pos(f_row, f_item, f_k0 + 1, f_par);
@@ -162,8 +161,9 @@ __global__ __launch_bounds__(256, 1) void sandwich4b_kernel(const S4Args g) {
             const unsigned b = !exists || !item_ok ? kParkedB
                                : !last ? base
                                : e0_ok ? (shift ? base - 8 : base) : kParkedB;
-            v[i][0] = b;
-            v[i][1] = row_ok ? b : kParkedB;
+            v[i][0] = b;                                           // row quads below N4 - 2: every row exists
+            v[i][1] = 4 * (N4 - 2) + f_row < L ? b : kParkedB;     // row quad N4 - 2
+            v[i][2] = 4 * (N4 - 1) + f_row < L ? b : kParkedB;     // row quad N4 - 1
             const unsigned at = (exists ? m : 0) * 128;
             const bool divert = !exists || (last && shift);
             const unsigned w0 = at + (divert ? 4 * SET + p0 : p0);
@@ -174,15 +174,14 @@ __global__ __launch_bounds__(256, 1) void sandwich4b_kernel(const S4Args g) {
 #pragma unroll
         for (int c = 0; c < 2; ++c) { rd[0][c] = rd_even + set_c[c]; rd[1][c] = rd_odd + set_c[c]; }
     };
-    // lane offsets of an Out fragment (D: row z, block y, column x).  Bit 0: last row quad, bit 1: last column quad
-    auto out_offsets = [&](unsigned quad, unsigned (&v)[4]) __attribute__((always_inline)) {
+    // lane offsets of an Out fragment (D: row z, block y, column x) of row quads below N4 - 2 / of row quad N4 - 2 / of
+    // row quad N4 - 1 (a row or item that does not exist is parked; the column is checked per group, see vo)
+    auto out_offsets = [&](unsigned quad, unsigned (&v)[3]) __attribute__((always_inline)) {
         const unsigned base = (unsigned)((z * g.out_row + y * g.out_item + x * g.out_col) * 8);
         const bool item_ok = quad * 4 + y < g.nitems;
-        const bool row_ok = rm == 0 || z < rm, col_ok = rm == 0 || x < rm;
         v[0] = item_ok ? base : kParkedB;
-        v[1] = item_ok && row_ok ? base : kParkedB;
-        v[2] = item_ok && col_ok ? base : kParkedB;
-        v[3] = item_ok && row_ok && col_ok ? base : kParkedB;
+        v[1] = item_ok && 4 * (N4 - 2) + z < M ? base : kParkedB;
+        v[2] = item_ok && 4 * (N4 - 1) + z < M ? base : kParkedB;
     };
 
     double ring[2][N4];         // In fragments of two row quads in MFMA lane order: parity of the row quad, k quad
@@ -197,15 +196,15 @@ __global__ __launch_bounds__(256, 1) void sandwich4b_kernel(const S4Args g) {
     //   write -- from there into r's transit set (the registers are free for row quad r + 2 afterwards);
     //   read  -- all of its fragments from that set into ring stage r & 1 (after a barrier behind everybody's writes).
     const unsigned pair0 = opaque((unsigned)wave * pair_step);
-    auto load_into = [&](auto rs, const unsigned (&v)[PW][2], auto R_, auto I_, double (&dst)[2]) __attribute__((always_inline)) {
+    auto load_into = [&](auto rs, const unsigned (&v)[PW][3], auto R_, auto I_, double (&dst)[2]) __attribute__((always_inline)) {
         constexpr int r = decltype(R_)::value, i = decltype(I_)::value;
         const unsigned s_off = opaque(r * ka_step) + pair0 + (unsigned)(4 * i) * pair_step;
-        const u32x4b q = __builtin_amdgcn_raw_buffer_load_b128(rs, (int)v[i][r == N4 - 1], (int)s_off, 0);
+        const u32x4b q = __builtin_amdgcn_raw_buffer_load_b128(rs, (int)v[i][r == N4 - 1 ? 2 : r == N4 - 2 ? 1 : 0], (int)s_off, 0);
         const f64x2b d = __builtin_bit_cast(f64x2b, q);
         dst[0] = d.x;
         dst[1] = d.y;
     };
-    auto load_pair = [&](auto rs, const unsigned (&v)[PW][2], auto R_, auto I_) __attribute__((always_inline)) {
+    auto load_pair = [&](auto rs, const unsigned (&v)[PW][3], auto R_, auto I_) __attribute__((always_inline)) {
         load_into(rs, v, R_, I_, stg[decltype(R_)::value & 1][decltype(I_)::value]);
     };
     auto write_from = [&](const unsigned (&w)[PW][2][2], auto R_, auto I_, auto H_, double val) __attribute__((always_inline)) {
@@ -246,29 +245,28 @@ __global__ __launch_bounds__(256, 1) void sandwich4b_kernel(const S4Args g) {
     // there and those of row quad ka + 5 are LOADED into the registers just freed -- row quads beyond the last are the
     // next item quad's (behind rs_nx, v_nx, w_nx, rd_nx).  Between two barriers the waves read row quads 2 D + 1 and
     // 2 D + 2 and write 2 D + 3 and 2 D + 4: four sets.  Every memory instruction behind an MFMA of its own.
-    auto quad_pass = [&](auto rs_in, auto rs_out, const unsigned (&v_out)[4], auto rs_nx, const unsigned (&v_nx)[PW][2],
-                         const unsigned (&w_nx)[PW][2][2], const unsigned (&rd_nx)[2][2], const unsigned (&v_in)[PW][2],
+    auto quad_pass = [&](auto rs_in, auto rs_out, const unsigned (&v_out)[3], auto rs_nx, const unsigned (&v_nx)[PW][3],
+                         const unsigned (&w_nx)[PW][2][2], const unsigned (&rd_nx)[2][2], const unsigned (&v_in)[PW][3],
                          const unsigned (&w_in)[PW][2][2], const unsigned (&rd_in)[2][2]) __attribute__((always_inline)) {
         double Y[N4][Q];
         double Yh[E ? N4 / 2 : 1];       // this wave's half of Y of the shared group: row quads 2 i + mpar
         double lf[2][N4];                // fragments of Lm for row quads pg (stage pg & 1) and pg + 1
         double ov[2][Q];                 // Out fragments of row quads pg and pg - 1
         double ovx[2] = {0.0, 0.0};      // those of the shared group (parity of the row quad; only mpar's is computed here)
-        // lane offsets of the groups' stores, for the interior row quads and for the last one
-        unsigned vo[2][Q], vox[2][2];
+        // lane offsets of the groups' stores for the three kinds of row quad (a column that does not exist is parked)
+        unsigned vo[3][Q], vox[2][3];
         unroll_b<0, Q>([&](auto J) __attribute__((always_inline)) {
             constexpr int j = decltype(J)::value;
-            const bool last_col = jg0 + j == N4 - 1;                  // wave-uniform
-            vo[0][j] = v_out[last_col ? 2 : 0];
-            vo[1][j] = v_out[last_col ? 3 : 1];
+            const bool col_ok = 4 * (jg0 + j) + x < M;
+#pragma unroll
+            for (int rv = 0; rv < 3; ++rv) vo[rv][j] = col_ok ? v_out[rv] : kParkedB;
         });
         if constexpr (E != 0) {
-            const bool last_col = jx == N4 - 1;
+            const bool col_ok = 4 * jx + x < M;
 #pragma unroll
-            for (int par = 0; par < 2; ++par) {                       // rows of the other parity are the partner's
-                vox[par][0] = par == mpar ? v_out[last_col ? 2 : 0] : kParkedB;
-                vox[par][1] = par == mpar ? v_out[last_col ? 3 : 1] : kParkedB;
-            }
+            for (int par = 0; par < 2; ++par)                         // rows of the other parity are the partner's
+#pragma unroll
+                for (int rv = 0; rv < 3; ++rv) vox[par][rv] = (par == mpar && col_ok) ? v_out[rv] : kParkedB;
         }
         auto store_frag = [&](unsigned vofs, unsigned s_off, double val) __attribute__((always_inline)) {
             __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2b, val), rs_out, (int)vofs, (int)s_off, 0);
@@ -370,10 +368,10 @@ __global__ __launch_bounds__(256, 1) void sandwich4b_kernel(const S4Args g) {
                     if constexpr (j == 0 && pg + 1 < N4) lf[b ^ 1][ka] = ltab[((pg + 1) * N4 + ka) * 16 + e_lane];
                     // row quad pg - 1 leaves: one store per two row quads of MFMAs
                     if constexpr (j == 1 && pg >= 1 && (ka & 1) && ka / 2 < Q)
-                        store_frag(vo[pg - 1 == N4 - 1][(ka / 2) % Q], s_prev + (unsigned)(jg0 + ka / 2) * jg_step,
+                        store_frag(vo[pg - 1 == N4 - 2 ? 1 : 0][(ka / 2) % Q], s_prev + (unsigned)(jg0 + ka / 2) * jg_step,
                                    ov[b ^ 1][(ka / 2) % Q]);
                     if constexpr (E != 0 && j == 1 && pg >= 1 && ka == 2 * Q + 1)
-                        store_frag(vox[b ^ 1][pg - 1 == N4 - 1], s_prev + (unsigned)jx * jg_step, ovx[b ^ 1]);
+                        store_frag(vox[b ^ 1][pg - 1 == N4 - 2 ? 1 : 0], s_prev + (unsigned)jx * jg_step, ovx[b ^ 1]);
                     __builtin_amdgcn_sched_barrier(0);
                 });
             });
@@ -383,15 +381,15 @@ __global__ __launch_bounds__(256, 1) void sandwich4b_kernel(const S4Args g) {
             const unsigned s_row = opaque((N4 - 1) * pg_step);
             unroll_b<0, Q>([&](auto J) __attribute__((always_inline)) {
                 constexpr int j = decltype(J)::value;
-                store_frag(vo[1][j], s_row + (unsigned)(jg0 + j) * jg_step, ov[b][j]);
+                store_frag(vo[2][j], s_row + (unsigned)(jg0 + j) * jg_step, ov[b][j]);
             });
-            if constexpr (E != 0) store_frag(vox[b][1], s_row + (unsigned)jx * jg_step, ovx[b]);
+            if constexpr (E != 0) store_frag(vox[b][2], s_row + (unsigned)jx * jg_step, ovx[b]);
         }
         __builtin_amdgcn_sched_barrier(0);
         QS_S4B_STAMP(255)
     };
 
-    unsigned v_in[PW][2], v_nx[PW][2], w_in[PW][2][2], w_nx[PW][2][2], rd_in[2][2], rd_nx[2][2], v_out[4];
+    unsigned v_in[PW][3], v_nx[PW][3], w_in[PW][2][2], w_nx[PW][2][2], rd_in[2][2], rd_nx[2][2], v_out[3];
     unsigned ph = 0;
     auto rs_in = rsrc(g.in - 1, iq, g.in_item);
     in_offsets(iq, true, ph, v_in, w_in, rd_in);
@@ -469,7 +467,7 @@ __global__ __launch_bounds__(256, 1) void sandwich4b_kernel(const S4Args g) {
         rs_in = rs_nx;
 #pragma unroll
         for (int i = 0; i < PW; ++i) {
-            v_in[i][0] = v_nx[i][0]; v_in[i][1] = v_nx[i][1];
+            v_in[i][0] = v_nx[i][0]; v_in[i][1] = v_nx[i][1]; v_in[i][2] = v_nx[i][2];
 #pragma unroll
             for (int c = 0; c < 2; ++c) { w_in[i][0][c] = w_nx[i][0][c]; w_in[i][1][c] = w_nx[i][1][c]; }
         }
