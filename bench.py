@@ -683,9 +683,10 @@ def run_rank(args):
         try:
             with open(prof) as f:
                 tr = json.load(f)
-            if tr.get("l") == l and tr.get("dtype") == args.dtype and tr.get("kernel", kernel) == kernel:
-                roofline["traffic"] = tr["hbm_bytes_per_launch"]
-                roofline["traffic_source"] = tr.get("source")
+            for ent in (tr if isinstance(tr, list) else [tr]):       # one entry per (size, dtype, kernel) profiled
+                if ent.get("l") == l and ent.get("dtype") == args.dtype and ent.get("kernel", kernel) == kernel:
+                    roofline["traffic"] = ent["hbm_bytes_per_launch"]
+                    roofline["traffic_source"] = ent.get("source")
         except Exception:
             pass
 
