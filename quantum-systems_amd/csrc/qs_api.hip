@@ -197,6 +197,7 @@ int qs_tuning_set(const char* key, int64_t value) {
     if (!strcmp(key, "slab_pair")) { g_tune.slab_pair = (int)value; return QS_OK; }
     if (!strcmp(key, "gemm_fast_persist")) { g_tune.gemm_fast_persist = (int)value; return QS_OK; }
     if (!strcmp(key, "gemm_fast_shape")) { g_tune.gemm_fast_shape = (int)value; return QS_OK; }
+    if (!strcmp(key, "gemm_pick")) { g_tune.gemm_pick = (int)value; return QS_OK; }
     if (!strcmp(key, "sandwich")) { g_tune.sandwich = (int)value; return QS_OK; }
     if (!strcmp(key, "sandwich_mode")) { g_tune.sandwich_mode = (int)value; return QS_OK; }
     if (!strcmp(key, "sandwich_t2")) { g_tune.sandwich_t2 = (int)value; return QS_OK; }

@@ -129,6 +129,7 @@ struct Tuning {
     int gemm_pipe = 1;           // 1: rotated K-loop schedule, 0: plain schedule (A/B reference)
     int gemm_fast = 1;           // 0 general kernel only, 1 automatic, 2 exact form only, 3 edge form wherever legal
     int gemm_fast_persist = 1;   // 0 one workgroup per tile, 1 automatic, 2 always persistent, >= 3 tiles per workgroup
+    int gemm_pick = 1;           // tile shape of the general kernel: 1 by rounds over the resident workgroups x tile work, 0 by padded area
     int gemm_fast_shape = 0;     // forces edge-form shape 1..N (0 = by padded-work cost)
     int gemm_skinny = 1;         // 0 disables the short-and-wide streaming product
     int gemm_stream = 1;         // 0 disables the small-coefficient streaming product, 2 = never split rows over two waves

@@ -35,6 +35,8 @@
 
 #include <type_traits>
 
+#include <cmath>
+
 #include "qs_common.h"
 
 namespace qs {
@@ -383,13 +385,19 @@ static bool fill_args(GemmArgs& g, const double* A, const double* B, double* C, 
 // ---------------------------------------------------------------------------
 struct TileShape { int id, bm, bn; double weight; };
 
-static int pick_shape(const TileShape* cand, int ncand, int64_t m, int64_t n) {
+// Tile shape of the smallest estimated time: rounds of the tile list over the resident workgroups (two per CU) times the
+// work of a tile over its relative rate.  For a long list that is the padded area, as before; for a short one -- the
+// single-particle functions of a 55-orbital dot on a 101 x 101 grid are a 55 x 10201 product: 80 tiles of 64 x 128 --
+// it prefers tiles that fill the chip (g_tune.gemm_pick == 0: padded area only, the round-1 rule).
+static int pick_shape(const TileShape* cand, int ncand, int64_t m, int64_t n, int64_t batch) {
     int best = cand[0].id;
     double best_cost = 1e300;
+    const double slots = 2.0 * device_cu_count();
     for (int i = 0; i < ncand; ++i) {
-        const double padded = (double)(cdiv(m, cand[i].bm) * cand[i].bm) *
-                              (double)(cdiv(n, cand[i].bn) * cand[i].bn);
-        const double cost = padded / cand[i].weight;
+        const double tiles = (double)cdiv(m, cand[i].bm) * (double)cdiv(n, cand[i].bn) * (double)batch;
+        const double area = (double)cand[i].bm * (double)cand[i].bn;
+        const double rounds = g_tune.gemm_pick == 0 ? tiles / slots : std::ceil(tiles / slots);
+        const double cost = rounds * area / cand[i].weight;
         if (cost < best_cost) { best_cost = cost; best = cand[i].id; }
     }
     return best;
@@ -437,7 +445,7 @@ int gemm_f64(const double* A, const double* B, double* C, int64_t m, int64_t n, 
             {1, 128, 128, 1.00}, {12, 96, 128, 0.98}, {13, 128, 96, 0.98}, {8, 96, 96, 0.96},
             {5, 64, 64, 0.95},   {9, 128, 64, 0.90},  {10, 64, 128, 0.90}, {11, 32, 32, 0.73},
         };
-        cfg = pick_shape(cand, sizeof(cand) / sizeof(cand[0]), m, n);
+        cfg = pick_shape(cand, sizeof(cand) / sizeof(cand[0]), m, n, batch);
     }
     return vec ? dispatch_f64<MODE_F64_VEC2>(cfg, g, batch, stream)
                : dispatch_f64<MODE_F64_SCALAR>(cfg, g, batch, stream);
@@ -462,7 +470,7 @@ int gemm_c128(const double* A, const double* B, double* C, int64_t m, int64_t n,
             {1, 64, 128, 1.00}, {2, 128, 64, 1.00}, {6, 64, 64, 1.00}, {9, 96, 96, 0.97},
             {7, 96, 64, 0.95},  {8, 64, 96, 0.95},  {4, 32, 32, 0.94},
         };
-        cfg = pick_shape(cand, sizeof(cand) / sizeof(cand[0]), m, n);
+        cfg = pick_shape(cand, sizeof(cand) / sizeof(cand[0]), m, n, batch);
     }
     switch (cfg) {
         case 1: return launch_one<2, 2, 2, 4, 8, MODE_C128>(g, batch, stream);   //  64 x 128
