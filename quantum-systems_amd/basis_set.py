@@ -57,21 +57,58 @@ def _deliver(t, np):
     return np.asarray(to_host(t))
 
 
-def _sole_owner(t):
-    """True when nothing but ``t`` itself can reach its storage: no view, no alias, no Python reference to the
-    tensor it aliases.  (A device array made by ``wrap`` is an alias of the tensor it was made from -- ``t._base``
-    -- and views of it attach to that base.)"""
+def _ownership_signature(t):
+    """Every count through which somebody else could reach the storage of ``t``: the storage's own use count (tensors
+    made with ``set_`` on it, views, the alias ``wrap`` makes), the tensor implementation's, and -- a device array made
+    by ``wrap`` is an alias of the tensor it was made from, ``t._base``, and views of it attach to that base -- the
+    base's Python references and implementation count.  The numbers themselves are CPython / PyTorch internals;
+    they are only ever compared with what the same function returns for a freshly made array nobody else holds
+    (``_UNSHARED`` below), so an interpreter that counts differently cannot turn sharing into "unshared"."""
+    base = t._base
+    return (
+        torch._C._storage_Use_Count(t.untyped_storage()._cdata),
+        t._use_count(),
+        base is not None,
+        sys.getrefcount(base) if base is not None else 0,
+        base._use_count() if base is not None else 0,
+        base is None or base._base is None,
+    )
+
+
+def _refs_to_attr(obj, slot):
+    """Python references to the array stored in ``obj.<slot>`` as counted from inside this helper (compared with the
+    count of an attribute nobody else holds, never with a literal)."""
+    arr = getattr(obj, slot)
+    return sys.getrefcount(arr)
+
+
+class _Holder:
+    pass
+
+
+def _calibrate_unshared():
+    """Signatures of arrays that are provably unshared, one per way a device array comes into being: wrapped by
+    ``wrap`` (an alias with a base) and returned by a tensor operation."""
+    sigs = set()
+    for make in (lambda: wrap(torch.empty(4)), lambda: wrap(torch.empty(4)) * 1):
+        h = _Holder()
+        h._x = make()
+        refs = _refs_to_attr(h, "_x")
+        sigs.add((refs,) + _ownership_signature(h._x))
+    return sigs
+
+
+_UNSHARED = _calibrate_unshared()
+
+
+def _sole_owner(obj, slot):
+    """True when nothing but ``obj.<slot>`` can reach the storage of the array stored there: no second Python
+    reference, no view, no storage-level alias.  Anything unexpected reads as "shared" (no donation)."""
+    refs = _refs_to_attr(obj, slot)
+    t = getattr(obj, slot)
     if t.storage_offset() != 0 or t.untyped_storage().nbytes() != t.numel() * t.element_size():
         return False
-    if t._use_count() != 1:
-        return False
-    base = t._base
-    if base is None:
-        return True
-    # nobody else holds the base: its Python object is referenced by this variable, getrefcount's argument and
-    # the tensor implementation's own slot (3; a user's variable makes it 4), the implementation by that object
-    # and by t's base link (2; every view adds one)
-    return sys.getrefcount(base) == 3 and base._use_count() == 2 and base._base is None
+    return (refs,) + _ownership_signature(t) in _UNSHARED
 
 
 def _module_of(np):
@@ -127,8 +164,9 @@ class BasisSet:
     sigma_z = _Checked(needs_spin=True, check=False)
 
     # change_basis reuses the storage of the tensor it drops from this many orbitals up (below, the fused
-    # small-basis passes are faster and memory is no concern); None of the reference's semantics change: the
-    # storage is only reused when no other reference to the old array exists
+    # small-basis passes are faster and memory is no concern; None switches the reuse off).  None of the reference's
+    # semantics change: the storage is only reused when no other reference, view or storage alias of the old array
+    # exists (_sole_owner)
     donate_u_from = 96
 
     def __init__(self, l, dim, np=None, includes_spin=False, anti_symmetrized_u=False):
@@ -139,6 +177,7 @@ class BasisSet:
         for slot in _ARRAY_FIELDS + ("_sigma_x", "_sigma_y", "_sigma_z"):
             setattr(self, slot, None)
         self._spin_2_tb_recipe = None
+        self._spin_2_tb_version = -1
         self._nuclear_repulsion_energy = 0
         self.particle_charge = -1  # electrons
         self._includes_spin = includes_spin
@@ -200,17 +239,25 @@ class BasisSet:
 
     @property
     def spin_2_tb(self):
-        """Two-body S^2.  At (2l)^4 complex elements it is as large as ``u``;
-        the spin doubling records how to build it and the tensor is produced on
-        first access (SURVEY 7 "memory capacity")."""
-        if self._spin_2_tb is None and self._spin_2_tb_recipe is not None and is_sharded_module(self.np):
-            self._spin_2_tb = sharded_basis.spin_2_tb_rows(self)      # this rank's rows only
+        """Two-body S^2.  At (2l)^4 complex elements it is as large as ``u``; the spin doubling records how to build
+        it -- ``sum_i S_i[p,r] S_i[q,s]`` (:745-747), minus the r <-> s term once anti-symmetrised (:525-526), from
+        three (2l, 2l) matrices -- and the tensor is produced on first access (SURVEY 7 "memory capacity").  The
+        recipe outlives the tensor it built for as long as nobody writes into that tensor: ``change_basis`` then
+        transforms the three matrices (O(l^3)) instead of the tensor (O(l^5), :379-382) and the tensor is rebuilt on the
+        next access."""
         if self._spin_2_tb is None and self._spin_2_tb_recipe is not None:
-            stack, anti = self._spin_2_tb_recipe
-            self._spin_2_tb_recipe = None
-            self._spin_2_tb = _deliver(
-                kernels.spin_squared_two_body(_stage(stack), antisymmetrize=anti), self.np
-            )
+            if is_sharded_module(self.np):
+                self._spin_2_tb = sharded_basis.spin_2_tb_rows(self)      # this rank's rows only
+                self._spin_2_tb_version = self._spin_2_tb.local._version
+            else:
+                stack, anti = self._spin_2_tb_recipe
+                self._spin_2_tb = _deliver(
+                    kernels.spin_squared_two_body(_stage(stack), antisymmetrize=anti), self.np
+                )
+                if isinstance(self._spin_2_tb, torch.Tensor):
+                    self._spin_2_tb_version = self._spin_2_tb._version
+                else:
+                    self._spin_2_tb_recipe = None      # a host array: writes into it cannot be noticed
         return self._spin_2_tb
 
     @spin_2_tb.setter
@@ -219,6 +266,21 @@ class BasisSet:
         assert all(self.check_axis_lengths(value, self.l))
         self._spin_2_tb_recipe = None
         self._spin_2_tb = value
+
+    def _spin_2_tb_recipe_valid(self):
+        """True while the recipe (three spin matrices + the anti-symmetry flag) still IS ``spin_2_tb``: the tensor has
+        not been built, or the copy handed out has not been written to since (the version counter of the device
+        tensor).  A recipe that no longer holds is dropped."""
+        if self._spin_2_tb_recipe is None:
+            return False
+        t = self._spin_2_tb
+        if t is None:
+            return True
+        loc = t.local if is_sharded(t) else t
+        if isinstance(loc, torch.Tensor) and loc._version == self._spin_2_tb_version:
+            return True
+        self._spin_2_tb_recipe = None
+        return False
 
     # --------------------------------------------------------- module plumbing
     @staticmethod
@@ -230,6 +292,8 @@ class BasisSet:
         uploads, device -> NumPy downloads."""
         self.np = np
         self.bra_spf  # materialise the lazy dual before converting, as :287 does
+        if self._spin_2_tb_recipe_valid():
+            self._spin_2_tb = None        # rebuilt in the new module on the next access: no (2l)^4 transfer
         for slot in _ARRAY_FIELDS:
             arr = getattr(self, slot)
             if slot in ("_u", "_spin_2_tb") and arr is not None and len(arr.shape) == 4:
@@ -352,23 +416,39 @@ class BasisSet:
         # reference, no view) its storage is reused: the transform runs in place with one spare buffer
         # instead of workspace + result -- 69 GB instead of 103 GB at l = 256.
         for slot in ("_u", "_spin_2_tb"):
-            if slot == "_spin_2_tb" and self.spin_2_tb is None:  # :379-382 (the property builds the lazy tensor)
+            if slot == "_spin_2_tb" and self._spin_2_tb_recipe_valid():
+                # :379-382 transforms the (2l)^4 tensor; it is sum_i S_i (x) S_i (minus the r <-> s term), so its
+                # transform is the same expression in S'_i = C~ S_i C: three one-body transforms, and the tensor is
+                # rebuilt from them when somebody asks for it.  (spin_x/y/z themselves keep their old values, 0.6.)
+                stack, anti = self._spin_2_tb_recipe
+                d_stack = _stage(stack)
+                c, ct = coeffs(d_stack)
+                self._spin_2_tb = None
+                self._spin_2_tb_recipe = (_deliver(kernels.transform_one_body(d_stack, c, ct), np), anti)
                 continue
+            if slot == "_spin_2_tb" and self.spin_2_tb is None:  # :379-382
+                continue
+            unshared = _sole_owner(self, slot)                    # (asked before `old` adds a reference of its own)
             old = getattr(self, slot)
             donate = (
-                type(self).transform_two_body_elements is BasisSet.transform_two_body_elements
+                unshared and self.donate_u_from is not None
+                and type(self).transform_two_body_elements is BasisSet.transform_two_body_elements
                 and is_device_module(np) and isinstance(old, torch.Tensor) and old.is_cuda
                 and len(old.shape) == 4 and old.is_contiguous()
                 and C.shape[1] <= C.shape[0] and C.shape[0] >= self.donate_u_from
                 and old.dtype == kernels.result_dtype(old, d_C, d_Ct)
-                and sys.getrefcount(old) <= 3                     # the attribute, `old`, the call's argument
-                and _sole_owner(old)
             )
             if donate:
                 setattr(self, slot, None)
                 plain = old.as_subclass(torch.Tensor)
                 del old
-                res = wrap(kernels.transform_two_body_(plain, d_C, d_Ct))
+                try:
+                    res = wrap(kernels.transform_two_body_(plain, d_C, d_Ct))
+                except BaseException:
+                    # refused before anything was launched (workspace allocation, argument checks): the tensor is
+                    # intact and stays the basis set's
+                    setattr(self, slot, wrap(plain))
+                    raise
                 del plain
             else:
                 res = self.transform_two_body_elements(old, d_C, np, C_tilde=d_Ct)
@@ -437,9 +517,10 @@ class BasisSet:
         on_device = d is self.u or isinstance(self.u, torch.Tensor)
         res = kernels.antisymmetrize(d, out=d if not on_device else None)
         self.u = _deliver(res, self.np)
-        if self._spin_2_tb_recipe is not None:
+        if self._spin_2_tb_recipe_valid():
             stack, _ = self._spin_2_tb_recipe
             self._spin_2_tb_recipe = (stack, True)
+            self._spin_2_tb = None                         # rebuilt anti-symmetrised on the next access
         elif self._spin_2_tb is not None:
             self.spin_2_tb = _deliver(kernels.antisymmetrize(_stage(self._spin_2_tb)), self.np)
         self._anti_symmetrized_u = True

@@ -14,6 +14,8 @@
 #include <stdio.h>
 #include <string.h>
 
+#include <mutex>
+
 #include "qs_common.h"
 
 namespace qs {
@@ -50,14 +52,18 @@ int device_cu_count() {
     return n;
 }
 
-int opt_in_dynamic_lds(const void* kern, size_t lds_bytes, PerDeviceOnce& once, const char* what) {
+int opt_in_dynamic_lds(const void* kern, size_t lds_bytes, PerDeviceLds& seen, const char* what) {
     if (lds_bytes <= 64 * 1024) return QS_OK;
-    const uint64_t bit = uint64_t(1) << current_device();
-    if (once.mask.load(std::memory_order_acquire) & bit) return QS_OK;
-    // a second thread racing here repeats the call, which is harmless
+    std::atomic<uint32_t>& top = seen.bytes[current_device()];
+    if (top.load(std::memory_order_acquire) >= lds_bytes) return QS_OK;
+    // slow path (a first launch, or one that needs more than any before it): serialised, so that the attribute and the
+    // record of it cannot end up in different orders when two threads raise the limit at once
+    static std::mutex raise;
+    std::lock_guard<std::mutex> hold(raise);
+    if (top.load(std::memory_order_relaxed) >= lds_bytes) return QS_OK;
     hipError_t e = hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
     if (e != hipSuccess) return hip_status(e, what);
-    once.mask.fetch_or(bit, std::memory_order_release);
+    top.store((uint32_t)lds_bytes, std::memory_order_release);
     return QS_OK;
 }
 
@@ -264,12 +270,21 @@ int qs_transform_two_body(int dtype, const void* u, const void* C, const void* C
         // T2 (L, L, M, M) goes to WA; the eligibility of the second pass is known before the first runs
         const int64_t MM = M * M;
         const int64_t n4 = cdiv(L, 4);
-        const bool second_ok = dtype == QS_F64 && L <= 64 && M <= 64 && n4 == cdiv(M, 4) && MM >= 1024 &&
-                               (4 * n4) * L * MM * 2 * 8 < (int64_t(1) << 31) &&
-                               (g_tune.sandwich >= 4 ? n4 >= 6 : n4 >= 9) &&
-                               // (15: both passes on slabs through the balanced kernel's instantiation for 16, or not at all)
-                               (n4 != 15 || (g_tune.sandwich_v2 != 0 && g_tune.sandwich_t2 != 0 && g_tune.sandwich != 3 &&
-                                             g_tune.sandwich != 6));
+        // the policy (where two fused passes measured faster) ...
+        const bool wanted = dtype == QS_F64 && L <= 64 && M <= 64 && n4 == cdiv(M, 4) && MM >= 1024 &&
+                            (4 * n4) * L * MM * 2 * 8 < (int64_t(1) << 31) &&
+                            (g_tune.sandwich >= 4 ? n4 >= 6 : n4 >= 9) &&
+                            // (15: both passes on slabs through the balanced kernel's instantiation for 16, or not at all)
+                            (n4 != 15 || (g_tune.sandwich_v2 != 0 && g_tune.sandwich_t2 != 0 && g_tune.sandwich != 3 &&
+                                          g_tune.sandwich != 6));
+        // ... and the kernel's own eligibility rule, asked of the kernel (dry run of the very calls made below), so the
+        // two can never disagree after the first pass has run: T2 transposed only if both passes take that layout
+        const bool second_nat = wanted && sandwich4_try(dtype, WA, out, Ct, 1, L, Ct, L, 1, MM, L, M, 1, L * MM, MM, 1,
+                                                        M * MM, MM, s, 1) == QS_OK;
+        const bool second_tr = wanted && g_tune.sandwich != 3 && g_tune.sandwich != 6 &&
+                               sandwich4_try(dtype, u, WA, C, M, 1, C, 1, M, L * L, L, M, L * L, L, 1, 1, M * L * L, L * L, s, 1) == QS_OK &&
+                               sandwich4_try(dtype, WA, out, Ct, 1, L, Ct, L, 1, MM, L, M, L * L, L, 1, 1, M * MM, MM, s, 1) == QS_OK;
+        const bool second_ok = second_nat || second_tr;
         if (second_ok) {
             void* T1s = (M < L) ? at(WA, wa, es) : out;     // scratch of the unfused fall-back of the first pass
             int rc2 = 1;
@@ -278,18 +293,18 @@ int qs_transform_two_body(int dtype, const void* u, const void* C, const void* C
             // way the second does.  Same-box sweep (profiles/r02_small_basis_sweep.txt): 4-10 % faster for
             // ceil(l/4) in {10, 13, 14, 16}, faster than the second pass alone for 11, slower for 9 and 12; 15 has
             // slab passes only (the balanced kernel's instantiation for 16).
-            const bool want_t2 = g_tune.sandwich_t2 >= 0 ? g_tune.sandwich_t2 != 0
-                                                         : (n4 == 10 || n4 == 11 || n4 >= 13);
+            const bool want_t2 = second_tr && (!second_nat || (g_tune.sandwich_t2 >= 0 ? g_tune.sandwich_t2 != 0
+                                                                                         : (n4 == 10 || n4 == 11 || n4 >= 13)));
             bool t2_transposed = false;
             if (g_tune.sandwich != 3 && g_tune.sandwich != 6) {
                 if (want_t2)
                     rc2 = sandwich4_try(dtype, u, WA, C, M, 1, C, 1, M, L * L, L, M, L * L, L, 1, 1, M * L * L, L * L, s);
-                else
+                else if (second_nat)
                     rc2 = sandwich4_try(dtype, u, WA, C, M, 1, C, 1, M, L * L, L, M, L * L, L, 1, MM, M, 1, s);
                 t2_transposed = want_t2 && rc2 != 1;
             }
-            if (rc2 == 1) {
-                // first pass on the 16-wide kernels (T1 in the spare buffer, T2 into WA)
+            if (rc2 == 1 && second_nat) {
+                // first pass on the 16-wide kernels (T1 in the spare buffer, T2 into WA, natural layout)
                 rc2 = slab_pair_try(dtype, u, C, WA, L * L, L, M, s);
                 if (rc2 == 1) {
                     rc2 = transpose_small(dtype, C, CT, L, M, s);
@@ -305,7 +320,9 @@ int qs_transform_two_body(int dtype, const void* u, const void* C, const void* C
             else
                 rc2 = sandwich4_try(dtype, WA, out, Ct, 1, L, Ct, L, 1, MM, L, M, 1, L * MM, MM, 1, M * MM, MM, s);
             if (rc2 != 1) return rc2;
-            return QS_ERR_HIP;    // unreachable: the second pass was checked eligible above
+            // not reached: the dry runs above ARE the kernel's eligibility rule for these very calls
+            snprintf(g_hip_err, sizeof(g_hip_err), "qs_transform_two_body: second fused pass refused after its dry run");
+            return QS_ERR_HIP;
         }
     }
 

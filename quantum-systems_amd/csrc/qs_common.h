@@ -44,13 +44,16 @@ int current_device();
 // than a kernel launch).
 int device_cu_count();
 
-// "Done once on device d" flags of one kernel instantiation (bit d of the mask).
-struct PerDeviceOnce {
-    std::atomic<uint64_t> mask{0};
+// Largest dynamic-LDS size one kernel instantiation has been opted in to, per device (0 = never).
+struct PerDeviceLds {
+    std::atomic<uint32_t> bytes[kMaxDevices];
+    PerDeviceLds() { for (auto& x : bytes) x.store(0); }
 };
 
-// Opt a kernel in to more than 64 KB of dynamic LDS on the current device, once per device.
-int opt_in_dynamic_lds(const void* kern, size_t lds_bytes, PerDeviceOnce& once, const char* what);
+// Opt a kernel in to more than 64 KB of dynamic LDS on the current device.  The attribute is raised again whenever a
+// launch asks for more than any earlier one did (kernels whose LDS size depends on run-time extents: spin2_tb,
+// gemm_skinny), and never lowered.
+int opt_in_dynamic_lds(const void* kern, size_t lds_bytes, PerDeviceLds& once, const char* what);
 
 // Workgroups of `kern` (256 threads, no dynamic LDS) resident per CU on the current device,
 // asked once per device and clamped to [1, 4]; `fallback` when the query fails.
@@ -96,10 +99,12 @@ int slab_pair_try(int dtype, const void* X, const void* B, void* Z, int64_t nsla
                   hipStream_t stream);
 
 // Fused pair of contractions on the 4-wide matrix instruction (qs_sandwich4.hip): Out_t = Lm . In_t . R for a batch
-// of L x L matrices with arbitrary element strides; L, M <= 64, ceil(L/4) == ceil(M/4).
+// of L x L matrices with arbitrary element strides; L, M <= 64, ceil(L/4) == ceil(M/4).  dry_run: launch nothing,
+// QS_OK = the call would launch.
 int sandwich4_try(int dtype, const void* in, void* out, const void* R, int64_t r_sk, int64_t r_sj, const void* Lm,
                   int64_t l_sp, int64_t l_sa, int64_t nitems, int64_t L, int64_t M, int64_t in_item, int64_t in_row,
-                  int64_t in_col, int64_t out_item, int64_t out_row, int64_t out_col, hipStream_t stream);
+                  int64_t in_col, int64_t out_item, int64_t out_row, int64_t out_col, hipStream_t stream,
+                  int dry_run = 0);
 
 // Short-and-wide streaming product (qs_gemm_skinny.hip): same return convention.
 int gemm_skinny_try(int dtype, const double* A, const double* B, double* C, int64_t m, int64_t n,

@@ -343,7 +343,7 @@ static int launch_one(GemmArgs g, int64_t batch, hipStream_t stream) {
     const int64_t nwg = (int64_t)g.tiles_m * g.tiles_n * batch;
     if (nwg <= 0 || nwg >= (int64_t(1) << 31)) return QS_ERR_BAD_EXTENT;
     const size_t lds = sizeof(double) * 2 * NP * (BM * (KT + 2) + KT * (BN + 16));
-    static PerDeviceOnce lds_opt_in[2];   // per instantiation, schedule and device
+    static PerDeviceLds lds_opt_in[2];   // per instantiation, schedule and device
     // the rotated schedule needs a second fragment set; shapes where that would
     // spill (8-byte staging with 16 accumulators, the 96x96 complex tile, the
     // 1-WG/CU tuning shapes) keep the plain schedule

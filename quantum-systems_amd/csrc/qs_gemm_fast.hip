@@ -511,7 +511,7 @@ static int launch_fast(const double* A, const double* B, double* C, int64_t m, i
     if (P > total) P = total;
     const size_t lds = sizeof(double) * 2 * NP * (BM * (KT + 2) + KT * (CX ? BN + 16 : BN));
     auto kern = gemm_fast_kernel<CX, TM, TN, VEC, EDGE>;
-    static PerDeviceOnce lds_opt_in;   // per instantiation and per device
+    static PerDeviceLds lds_opt_in;   // per instantiation and per device
     if (int rc = opt_in_dynamic_lds((const void*)kern, lds, lds_opt_in, "hipFuncSetAttribute(gemm_fast)")) return rc;
     hipLaunchKernelGGL(kern, dim3((unsigned)P), dim3(256), lds, stream, g);
     note_dispatch("qs::gemm_fast_kernel<%s, %d, %d, %s, %s>", CX ? "true" : "false", TM, TN, VEC ? "true" : "false",

@@ -168,7 +168,7 @@ static int launch_skinny(const double* A, const double* B, double* C, int64_t n,
     if (nwg <= 0 || nwg >= (int64_t(1) << 31)) return QS_ERR_BAD_EXTENT;
     const size_t lds = sizeof(double) * NP * M * (k + 2);
     auto kern = gemm_skinny_kernel<CX, TMS>;
-    static PerDeviceOnce lds_opt_in;
+    static PerDeviceLds lds_opt_in;
     if (int rc = opt_in_dynamic_lds((const void*)kern, lds, lds_opt_in, "hipFuncSetAttribute(gemm_skinny)")) return rc;
     hipLaunchKernelGGL(kern, dim3((unsigned)nwg), dim3(256), lds, stream, g);
     note_dispatch("qs::gemm_skinny_kernel<%s, %d>", CX ? "true" : "false", TMS);

@@ -204,6 +204,7 @@ __global__ __launch_bounds__(1024) void spin2_tb_kernel(const f64x2* __restrict_
     // (and S_i[p, s] for the exchange term) are read from LDS once per column, only the row factors S_i[p, r] /
     // S_i[q, r] (one address per wave: a broadcast) per row.
     const int ts = threadIdx.x % cw, tr = threadIdx.x / cw, rg = blockDim.x / cw;
+    if (tr >= rg) return;     // cw does not divide the workgroup: the surplus lanes would repeat rows of row group 0
     for (int s = ts; s < n; s += cw) {
         f64x2 qs[3], ps[3];
 #pragma unroll
@@ -320,7 +321,7 @@ int spin2_two_body(const void* S, void* out, int64_t n, int64_t p_lo, int64_t p_
     if (nwg >= (int64_t(1) << 31)) return QS_ERR_BAD_EXTENT;
     const size_t lds = sizeof(double) * 2 * 6 * n;       // rows p and q of S_x, S_y, S_z: 96 n bytes
     if (lds > 160 * 1024) return QS_ERR_BAD_EXTENT;      // n <= 1706 spin orbitals (LDS of one CU)
-    static PerDeviceOnce lds_opt_in;                     // beyond 64 KB (n > 682) the kernel opts in, per device
+    static PerDeviceLds lds_opt_in;                     // beyond 64 KB (n > 682) the kernel opts in, per device
     if (int rc = opt_in_dynamic_lds((const void*)spin2_tb_kernel, lds, lds_opt_in, "hipFuncSetAttribute(spin2_tb)"))
         return rc;
     // beyond 64 KB of LDS one workgroup fits a CU: make it 1024 threads so that the CU still has 16 waves in flight

@@ -23,7 +23,7 @@ struct S4Args {
 
 // The balanced form with a cooperative fetch (qs_sandwich4b.hip): slabs in (in_col == 1), instantiations for n4 in
 // {10, 12, 14, 16}, each for 4 (n4 - 2) < L, M <= 4 n4.
-// QS_OK / error after launching, 1 = no such instantiation.
-int sandwich4b_launch(const S4Args& g, int n4, hipStream_t stream);
+// QS_OK / error after launching, 1 = no such instantiation; with `dry_run` nothing is launched (QS_OK = would launch).
+int sandwich4b_launch(const S4Args& g, int n4, hipStream_t stream, int dry_run);
 
 }  // namespace qs

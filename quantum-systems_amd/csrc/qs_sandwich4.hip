@@ -520,7 +520,8 @@ __global__ __launch_bounds__(256, 1) void sandwich4_kernel(const S4Args g) {
 }
 
 template <int N4>
-static int launch_sandwich4(const S4Args& g, hipStream_t stream) {
+static int launch_sandwich4(const S4Args& g, hipStream_t stream, int dry_run) {
+    if (dry_run) return QS_OK;
     const int n_cu = device_cu_count();
     int64_t wgs = n_cu - n_cu % 8;                       // one workgroup (four waves, one per SIMD) per CU
     if (wgs < 8) wgs = 8;
@@ -531,7 +532,7 @@ static int launch_sandwich4(const S4Args& g, hipStream_t stream) {
     const int64_t need = (units + gran - 1) / gran * gran;
     if (wgs > need) wgs = need;                          // short item lists: no idle workgroups
     const size_t lds = sizeof(double) * (2 * N4 * N4 * 16 + 4 * 2 * (2 * ((N4 + 1) / 2)) * 64);
-    static PerDeviceOnce lds_opt_in;
+    static PerDeviceLds lds_opt_in;
     if (int rc = opt_in_dynamic_lds((const void*)sandwich4_kernel<N4>, lds, lds_opt_in, "hipFuncSetAttribute(sandwich4)"))
         return rc;
     hipLaunchKernelGGL(sandwich4_kernel<N4>, dim3((unsigned)wgs), dim3(256), lds, stream, g);
@@ -540,9 +541,11 @@ static int launch_sandwich4(const S4Args& g, hipStream_t stream) {
 }
 
 // Out_t = Lm . In_t . R for t < nitems (strides in elements); QS_OK / error after launching, 1 = not eligible.
+// With `dry_run` nothing is launched: QS_OK = this call would launch (the ONE eligibility rule, asked by
+// qs_transform_two_body before it commits the intermediate to the layout of the second fused pass).
 int sandwich4_try(int dtype, const void* in, void* out, const void* R, int64_t r_sk, int64_t r_sj, const void* Lm,
                   int64_t l_sp, int64_t l_sa, int64_t nitems, int64_t L, int64_t M, int64_t in_item, int64_t in_row,
-                  int64_t in_col, int64_t out_item, int64_t out_row, int64_t out_col, hipStream_t stream) {
+                  int64_t in_col, int64_t out_item, int64_t out_row, int64_t out_col, hipStream_t stream, int dry_run) {
     if (dtype != QS_F64) return 1;
     if (L < 1 || M < 1 || L > 64 || M > 64) return 1;
     const int n4 = (int)cdiv(L, 4);
@@ -593,24 +596,24 @@ int sandwich4_try(int dtype, const void* in, void* out, const void* R, int64_t r
     // (the (d, c) pass): a workgroup per quad keeps its four fetch streams on the same lines
     g.mode = g_tune.sandwich_mode >= 0 ? g_tune.sandwich_mode : (in_item == 1 ? 3 : 0);
     if (v2) {
-        const int rc = sandwich4b_launch(g, n4k, stream);
+        const int rc = sandwich4b_launch(g, n4k, stream, dry_run);
         if (rc != 1) return rc;
     }
     switch (n4) {
 #ifdef QS_S4_ONLY          // development builds: one instantiation compiles in seconds
-        case QS_S4_ONLY: return launch_sandwich4<QS_S4_ONLY>(g, stream);
+        case QS_S4_ONLY: return launch_sandwich4<QS_S4_ONLY>(g, stream, dry_run);
 #else
-        case 6: return launch_sandwich4<6>(g, stream);
-        case 7: return launch_sandwich4<7>(g, stream);
-        case 8: return launch_sandwich4<8>(g, stream);
-        case 9: return launch_sandwich4<9>(g, stream);
-        case 10: return launch_sandwich4<10>(g, stream);
-        case 11: return launch_sandwich4<11>(g, stream);
-        case 12: return launch_sandwich4<12>(g, stream);
-        case 13: return launch_sandwich4<13>(g, stream);
-        case 14: return launch_sandwich4<14>(g, stream);
-        case 15: return launch_sandwich4<15>(g, stream);
-        case 16: return launch_sandwich4<16>(g, stream);
+        case 6: return launch_sandwich4<6>(g, stream, dry_run);
+        case 7: return launch_sandwich4<7>(g, stream, dry_run);
+        case 8: return launch_sandwich4<8>(g, stream, dry_run);
+        case 9: return launch_sandwich4<9>(g, stream, dry_run);
+        case 10: return launch_sandwich4<10>(g, stream, dry_run);
+        case 11: return launch_sandwich4<11>(g, stream, dry_run);
+        case 12: return launch_sandwich4<12>(g, stream, dry_run);
+        case 13: return launch_sandwich4<13>(g, stream, dry_run);
+        case 14: return launch_sandwich4<14>(g, stream, dry_run);
+        case 15: return launch_sandwich4<15>(g, stream, dry_run);
+        case 16: return launch_sandwich4<16>(g, stream, dry_run);
 #endif
         default: return 1;
     }

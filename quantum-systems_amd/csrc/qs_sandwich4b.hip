@@ -478,14 +478,15 @@ __global__ __launch_bounds__(256, 1) void sandwich4b_kernel(const S4Args g) {
 }
 
 template <int N4>
-static int launch_sandwich4b(const S4Args& g, hipStream_t stream) {
+static int launch_sandwich4b(const S4Args& g, hipStream_t stream, int dry_run) {
+    if (dry_run) return QS_OK;
     const int n_cu = device_cu_count();
     int64_t wgs = n_cu - n_cu % 8;                       // one workgroup (four waves, one per SIMD) per CU
     if (wgs < 8) wgs = 8;
     const int64_t need = ((int64_t)g.nquads + 7) / 8 * 8;
     if (wgs > need) wgs = need;                          // short item lists: no idle workgroups
     const size_t lds = sizeof(double) * (2 * N4 * N4 * 16 + 8 * N4 * 64 + ((N4 % 4) ? 2 * N4 * 64 : 0));
-    static PerDeviceOnce lds_opt_in;
+    static PerDeviceLds lds_opt_in;
     if (int rc = opt_in_dynamic_lds((const void*)sandwich4b_kernel<N4>, lds, lds_opt_in, "hipFuncSetAttribute(sandwich4b)"))
         return rc;
     hipLaunchKernelGGL(sandwich4b_kernel<N4>, dim3((unsigned)wgs), dim3(256), lds, stream, g);
@@ -493,16 +494,16 @@ static int launch_sandwich4b(const S4Args& g, hipStream_t stream) {
     return launch_status("sandwich4b launch");
 }
 
-int sandwich4b_launch(const S4Args& g, int n4, hipStream_t stream) {
+int sandwich4b_launch(const S4Args& g, int n4, hipStream_t stream, int dry_run) {
     if (g.in_col != 1) return 1;
     switch (n4) {
 #ifdef QS_S4_ONLY          // development builds: one instantiation compiles in seconds
-        case QS_S4_ONLY: return launch_sandwich4b<QS_S4_ONLY>(g, stream);
+        case QS_S4_ONLY: return launch_sandwich4b<QS_S4_ONLY>(g, stream, dry_run);
 #else
-        case 10: return launch_sandwich4b<10>(g, stream);
-        case 12: return launch_sandwich4b<12>(g, stream);
-        case 14: return launch_sandwich4b<14>(g, stream);
-        case 16: return launch_sandwich4b<16>(g, stream);
+        case 10: return launch_sandwich4b<10>(g, stream, dry_run);
+        case 12: return launch_sandwich4b<12>(g, stream, dry_run);
+        case 14: return launch_sandwich4b<14>(g, stream, dry_run);
+        case 16: return launch_sandwich4b<16>(g, stream, dry_run);
 #endif
         default: return 1;
     }

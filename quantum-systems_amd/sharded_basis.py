@@ -60,7 +60,14 @@ def change_basis(bs, C, C_tilde=None):
     u = bs._u if is_sharded(bs._u) else np.shard(bs._u)
     bs.u = transform_two_body(u, d_C, d_Ct, np)
     del u
-    if bs.spin_2_tb is not None:                                # :379-382
+    if bs._spin_2_tb_recipe_valid():
+        # :379-382 on the recipe: spin_2_tb = sum_i S_i (x) S_i (- r <-> s), so its transform is the same expression in
+        # S'_i = C~ S_i C -- three replicated one-body transforms, no second O(l^5) transform, no second slab
+        stack, anti = bs._spin_2_tb_recipe
+        S = _plain(np.asarray(stack)).to(_C128).contiguous()
+        bs._spin_2_tb = None
+        bs._spin_2_tb_recipe = (wrap(eng.transform_one_body(S, d_C.to(_C128), d_Ct.to(_C128))), anti)
+    elif bs.spin_2_tb is not None:                              # :379-382
         bs.spin_2_tb = transform_two_body(bs._spin_2_tb, d_C, d_Ct, np)
     if bs.position is not None:
         bs.position = one_body(bs.position)
@@ -82,9 +89,10 @@ def anti_symmetrize_two_body_elements(bs):
     eng = bs.np.engine
     u = bs._u
     bs.u = u._like(eng.antisymmetrize(u.local))
-    if bs._spin_2_tb_recipe is not None:
+    if bs._spin_2_tb_recipe_valid():
         stack, _ = bs._spin_2_tb_recipe
         bs._spin_2_tb_recipe = (stack, True)
+        bs._spin_2_tb = None                                     # rebuilt anti-symmetrised on the next access
     elif bs._spin_2_tb is not None:
         t = bs._spin_2_tb
         bs.spin_2_tb = t._like(eng.antisymmetrize(t.local))
@@ -94,8 +102,7 @@ def anti_symmetrize_two_body_elements(bs):
 def spin_2_tb_rows(bs):
     """This rank's rows of the two-body S^2 (basis_set.py:745-747), built from the (3, n, n) spin matrices."""
     np = bs.np
-    stack, anti = bs._spin_2_tb_recipe
-    bs._spin_2_tb_recipe = None
+    stack, anti = bs._spin_2_tb_recipe            # (kept: change_basis transforms the recipe, not the rows)
     S = _plain(np.asarray(stack)).to(_C128).contiguous()
     n = S.shape[-1]
     lo, hi = sharded.SlabPartition(n, np.world).bounds(np.rank)

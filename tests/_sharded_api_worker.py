@@ -120,6 +120,9 @@ def main():
 
     gos.change_basis(mod.asarray(g["C"]))                     # u AND spin_2_tb transformed (:374-382)
     assert gos.l == int(g["l_after"])
+    # ... spin_2_tb as its recipe (three transformed spin matrices): no second all-to-all, no second slab; the rows
+    # read above were dropped and are rebuilt on access
+    assert gb._spin_2_tb is None and tuple(gb._spin_2_tb_recipe[0].shape) == (3, 8, 8)
     uc = gos.u
     assert uc.axis == 1                                       # one all-to-all: the sharded index flipped
     np.testing.assert_allclose(N(uc.local), rows_of(g["cb_u"], uc), rtol=1e-10, atol=1e-12)

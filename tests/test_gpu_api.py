@@ -149,12 +149,59 @@ def test_gos_golden_then_change_basis_on_spin_basis(mod, golden):
     # spin one-body operators left alone (:368-372)
     gos.change_basis(m.asarray(g["C"]))
     assert gos.l == int(g["l_after"])
+    if mod == "hip":
+        # spin_2_tb went through change_basis as its RECIPE (three transformed spin matrices), not as a second
+        # four-index transform of a (2l)^4 tensor; the tensor read above was dropped and is rebuilt on access
+        assert gb._spin_2_tb is None and gb._spin_2_tb_recipe is not None
+        assert tuple(gb._spin_2_tb_recipe[0].shape) == (3, 8, 8) and gb._spin_2_tb_recipe[1] is True
     for k in ("h", "s", "u", "position", "spin_2_tb"):
         np.testing.assert_allclose(H(getattr(gb, k)), g["cb_" + k], rtol=1e-10, atol=1e-12)
     for k in ("spin_x", "spin_y", "spin_z", "spin_2"):
         got = H(getattr(gb, k))
         assert got.shape == (10, 10)
         np.testing.assert_allclose(got, g["cb_" + k], rtol=1e-13, atol=1e-14)
+
+
+def test_spin_2_tb_recipe_gives_way_to_a_tensor_somebody_wrote_into(golden):
+    # the recipe stands for the tensor only while nobody has changed the tensor: after an in-place write the
+    # reference's route (:379-382, the four-index transform of the tensor itself) is taken and the write survives
+    from quantum_systems_amd import kernels as K
+
+    g = golden("gos_l5_default_spinors")
+    bs = basis_from(g, "in_", 5, 2, hip)
+    gos = SpatialOrbitalSystem(4, bs).construct_general_orbital_system()
+    gb = gos._basis_set
+    tb = gos.spin_2_tb
+    assert gb._spin_2_tb_recipe is not None and gb._spin_2_tb_recipe_valid()
+    tb[1, 2, 3, 4] += 0.5
+    changed = H(tb).copy()
+    gos.change_basis(hip.asarray(g["C"]))
+    assert gb._spin_2_tb_recipe is None and gb._spin_2_tb is not None
+    np.testing.assert_allclose(H(gos.spin_2_tb), orc.transform_two_body(changed, g["C"]), rtol=1e-10, atol=1e-12)
+    # a basis whose spin_2_tb was never read: recipe in, recipe out, no (2l)^4 tensor ever built -- and the
+    # rectangular C of the fixture (10 -> 8) lands in the recipe's shape
+    bs = basis_from(g, "in_", 5, 2, hip)
+    gos = SpatialOrbitalSystem(4, bs).construct_general_orbital_system()
+    gb = gos._basis_set
+    calls, real = [], (K.transform_two_body, K.transform_two_body_)
+
+    def counted(fn):
+        def inner(*a, **k):
+            calls.append(fn.__name__)
+            return fn(*a, **k)
+        return inner
+
+    K.transform_two_body, K.transform_two_body_ = counted(real[0]), counted(real[1])
+    try:
+        gos.change_basis(hip.asarray(g["C"]))
+    finally:
+        K.transform_two_body, K.transform_two_body_ = real
+    assert len(calls) == 1                                    # u only: ONE four-index transform per change_basis
+    assert gb._spin_2_tb is None and tuple(gb._spin_2_tb_recipe[0].shape) == (3, 8, 8)
+    np.testing.assert_allclose(H(gos.spin_2_tb), g["cb_spin_2_tb"], rtol=1e-10, atol=1e-12)
+    # copies keep working on their own
+    twin = gos.copy_system()
+    np.testing.assert_allclose(H(twin.spin_2_tb), g["cb_spin_2_tb"], rtol=1e-10, atol=1e-12)
 
 
 @pytest.mark.parametrize("mod", MODULES)
@@ -387,6 +434,35 @@ def test_change_basis_reuses_the_storage_of_the_tensor_it_drops():
     view = bs.u[0]
     bs.change_basis(hip.asarray(C))
     assert np.array_equal(H(view), u[0])
+    # ... and so does a tensor built on the same storage without being a view
+    bs = system()
+    raw = torch.as_tensor(bs.u)
+    alias = torch.empty(0, dtype=raw.dtype, device=raw.device).set_(raw.untyped_storage(), 0, tuple(raw.shape))
+    del raw
+    bs.change_basis(hip.asarray(C))
+    assert np.array_equal(alias.cpu().numpy(), u)
+    del alias
+    # the reuse can be switched off
+    bs = system()
+    bs.donate_u_from = None
+    ptr = torch.as_tensor(bs.u).data_ptr()
+    bs.change_basis(hip.asarray(C))
+    assert torch.as_tensor(bs.u).data_ptr() != ptr
+    # a refusal before anything is launched leaves the tensor with the basis set
+    bs = system()
+    ptr = torch.as_tensor(bs.u).data_ptr()
+    real = K.transform_two_body_
+
+    def refuse(*a, **k):
+        raise RuntimeError("no workspace")
+
+    K.transform_two_body_ = refuse
+    try:
+        with pytest.raises(RuntimeError, match="no workspace"):
+            bs.change_basis(hip.asarray(C))
+    finally:
+        K.transform_two_body_ = real
+    assert bs.u is not None and torch.as_tensor(bs.u).data_ptr() == ptr and np.array_equal(H(bs.u), u)
     # shrinking basis: result at the start of the old storage; growing basis / complex C on a real u: ordinary path
     bs = system()
     ptr = torch.as_tensor(bs.u).data_ptr()

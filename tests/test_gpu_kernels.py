@@ -677,6 +677,30 @@ def test_replicated_layout_matches_full_transform(K):
             assert (slab - full[lo:hi]).abs().max().item() <= 1e-12 * full.abs().max().item()
 
 
+def test_dynamic_lds_limit_is_raised_when_a_later_call_needs_more(K):
+    # kernels whose LDS size depends on run-time extents (spin2_tb: 96 n bytes; gemm_skinny:
+    # 8 NP m (k + 2)) used to opt in to the FIRST call's size only, so a later, larger call failed with QS_ERR_HIP.
+    g = torch.Generator(device="cuda:0").manual_seed(77)
+    for n in (700, 1100):                                   # 67 KB, then 106 KB in the same process
+        S = torch.complex(torch.randn(3, n, n, dtype=torch.float64, device="cuda:0", generator=g),
+                          torch.randn(3, n, n, dtype=torch.float64, device="cuda:0", generator=g))
+        rows = K.spin_squared_two_body(S, antisymmetrize=True, p_lo=n - 1, p_hi=n)
+        assert K.last_dispatch() == "qs::spin2_tb_kernel"
+        q = n // 3
+        ref = (sum(torch.outer(S[k, n - 1], S[k, q]) for k in range(3))
+               - sum(torch.outer(S[k, q], S[k, n - 1]) for k in range(3)))
+        assert (rows[0, q] - ref).abs().max().item() <= 1e-13 * 3 * S.abs().max().item() ** 2
+        del rows, S
+    rng = np.random.default_rng(5)
+    m, n = 16, 1 << 16
+    for k in (260, 512):                                    # complex, 16 rows: 67 KB, then 132 KB
+        A = rng.standard_normal((m, k)) + 1j * rng.standard_normal((m, k))
+        B = rng.standard_normal((k, n)) + 1j * rng.standard_normal((k, n))
+        got = K.matmul(dev(A), dev(B))
+        assert "gemm_skinny_kernel<true, 1>" in K.last_dispatch()
+        assert relerr(host(got), A @ B) <= 1e-13
+
+
 def test_spin_squared_two_body_with_1024_spin_orbitals(K):
     # n = 1024 (l = 512 spatial orbitals, BASELINE.json configs[4]): the rows of S_x, S_y, S_z staged per workgroup
     # need 96 KB of LDS -- the kernel opts in beyond 64 KB (per device) instead of refusing n > 682

@@ -269,3 +269,38 @@ def test_two_dim_one_body_generators_match_reference():
         tab = td.spf_state(R, T, p, 1, 1)
         np.testing.assert_allclose(tab[tuple(pts.T)], g["spf_files_val"][p], rtol=1e-7, atol=1e-12)
         np.testing.assert_allclose(np.abs(tab).sum(), g["spf_files_abs_sum"][p], rtol=1e-9)
+
+
+def test_storage_donation_only_for_provably_unshared_arrays():
+    # change_basis may overwrite the tensor it drops only when nothing else can reach its storage: a second
+    # Python reference, a view, a tensor built on the same storage with set_, or a user-held base all read as shared.
+    # The counts are compared with those of a fresh array measured at import, never with literals.
+    import torch
+
+    from quantum_systems_amd import basis_set as B
+    from quantum_systems_amd.array_module import wrap
+
+    class Holder:
+        pass
+
+    h = Holder()
+    h._u = wrap(torch.zeros(8, dtype=torch.float64))
+    assert B._sole_owner(h, "_u")
+    keep = h._u
+    assert not B._sole_owner(h, "_u")
+    del keep
+    view = h._u[:2]
+    assert not B._sole_owner(h, "_u")
+    del view
+    alias = torch.empty(0, dtype=torch.float64).set_(h._u.untyped_storage(), 0, (8,))
+    assert not B._sole_owner(h, "_u")
+    del alias
+    assert B._sole_owner(h, "_u")
+    h._u = wrap(torch.zeros(8, dtype=torch.float64)) + 1          # the result of a tensor operation
+    assert B._sole_owner(h, "_u")
+    base = torch.zeros(8, dtype=torch.float64)
+    h._u = wrap(base)                                              # the user still holds the tensor it aliases
+    assert not B._sole_owner(h, "_u")
+    h._u = wrap(torch.zeros(16, dtype=torch.float64))[4:12]        # not the whole storage
+    assert not B._sole_owner(h, "_u")
+    assert len(B._UNSHARED) >= 1 and all(isinstance(sig, tuple) for sig in B._UNSHARED)

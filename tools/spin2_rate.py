@@ -1,6 +1,7 @@
 """Rate of the two-body S^2 kernel (16 n^4 bytes written): rows of a (n, n, n, n) complex128 tensor."""
+import os
 import sys
-sys.path.insert(0, ".")
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
 import torch
 from quantum_systems_amd import kernels as K
 for n, rows in ((512, 16), (1024, 2), (110, 110)):
