@@ -106,6 +106,8 @@ def _sole_owner(obj, slot):
     reference, no view, no storage-level alias.  Anything unexpected reads as "shared" (no donation)."""
     refs = _refs_to_attr(obj, slot)
     t = getattr(obj, slot)
+    if not isinstance(t, torch.Tensor):
+        return False
     if t.storage_offset() != 0 or t.untyped_storage().nbytes() != t.numel() * t.element_size():
         return False
     return (refs,) + _ownership_signature(t) in _UNSHARED
@@ -248,7 +250,7 @@ class BasisSet:
         if self._spin_2_tb is None and self._spin_2_tb_recipe is not None:
             if is_sharded_module(self.np):
                 self._spin_2_tb = sharded_basis.spin_2_tb_rows(self)      # this rank's rows only
-                self._spin_2_tb_version = self._spin_2_tb.local._version
+                self._spin_2_tb_version = self._spin_2_tb.rows._version
             else:
                 stack, anti = self._spin_2_tb_recipe
                 self._spin_2_tb = _deliver(
@@ -276,7 +278,7 @@ class BasisSet:
         t = self._spin_2_tb
         if t is None:
             return True
-        loc = t.local if is_sharded(t) else t
+        loc = t.rows if is_sharded(t) else t
         if isinstance(loc, torch.Tensor) and loc._version == self._spin_2_tb_version:
             return True
         self._spin_2_tb_recipe = None
@@ -487,7 +489,7 @@ class BasisSet:
     def anti_symmetrize_u(_u):
         """``u[pqrs] - u[pqsr]`` as a new array (:776-778)."""
         if is_sharded(_u):
-            return _u._like(kernels.antisymmetrize(_u.local))
+            return _u._like(kernels.antisymmetrize(_u.rows))
         out = kernels.antisymmetrize(_stage(_u))
         if isinstance(_u, torch.Tensor):
             return wrap(out)

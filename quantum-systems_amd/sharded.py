@@ -398,6 +398,129 @@ def transform_two_body_sharded_inplace(u_bslab, C, C_tilde=None, rank=0, world=1
 
 
 # ---------------------------------------------------------------------------
+# The layout behind the API (ShardedDeviceModule): rows of one leading index in, rows of the other one out,
+# streamed so that a rank never holds more than its input rows, its output rows and O(l^3) of scratch.
+# ---------------------------------------------------------------------------
+
+# Scratch the streamed transform may use per rank (t1, t2, the send block and the receive staging, each
+# chunk_rows * l^3 elements).  A constant, not a query of free memory: every rank must derive the same chunking.
+STREAM_BUDGET_BYTES = 8 << 30
+
+
+def rows_buffer_elems(L, M, jl):
+    """Elements of the result buffer of ``transform_two_body_rows`` for ``jl`` result rows: the rows themselves,
+    room for the received rows while they are still (L, M, M) each, and one spare received row (see there)."""
+    return jl * max(L, M) * M * M + L * M * M
+
+
+def stream_chunk_rows(L, M, il_max, elem_bytes, budget_bytes=None):
+    """Input rows handled per exchange step: as many as the scratch budget allows (all of them when the tensor is
+    small: one exchange, today's out-of-place behaviour), at least one."""
+    budget = STREAM_BUDGET_BYTES if budget_bytes is None else budget_bytes
+    unit = max(L * L * M, L * M * M, M * M * M) * elem_bytes
+    return int(max(1, min(il_max, budget // (4 * unit))))
+
+
+def transform_two_body_rows(rows, C, C_tilde=None, rank=0, world=1, group=None, engine=HipEngine, in_part=None,
+                            chunk_rows=None, out=None):
+    """The four-index transform of a tensor sharded over ONE of its two leading indices, result sharded over the
+    OTHER one, with everything but the input rows and the result rows O(l^3) -- the layout behind
+    ``ShardedDeviceModule`` (``change_basis`` of a sharded basis set, basis_set.py:374-382, and the per-step
+    functional call of a solver, system.py:222-225, which keeps ``u`` resident).
+
+    ``rows[i, j, c, d]``: this rank's rows ``i`` of the sharded index I (split ``in_part``, balanced by default),
+    the other leading index J whole -- ``u[a_lo + i, j]`` for a leading-index sharding, ``u[j, b_lo + i]`` for a
+    second-index sharding (``ShardedTensor4.rows``).  The transform is symmetric under swapping its two leading
+    index pairs (both are contracted with ``C_tilde``), so the same code serves both.  Returns
+    ``out_rows[j', i', r, s]`` for this rank's rows ``j'`` of the transformed index J' (balanced split of M), I'
+    whole: the sharded index has flipped.
+
+    Per step of ``chunk_rows`` input rows (three l^3-sized temporaries per row):
+      d, c   ``t2[i][j][r, s] = C[c, r] rows[i][j][c, d] C[d, s]``                        (slab-local)
+      J      ``W[j', i, (r,s)] = Ct[j', j] t2[i][j][(r,s)]``                               (J is whole on this rank)
+      send   the rows ``j'`` of W that rank g owns go to g -- W is stored ``[j'][i][(r,s)]``, so a peer's share is one
+             contiguous block, no packing -- and what the peers computed for OUR ``j'`` lands in
+             ``R[j'_loc][i_global][(r,s)]``                                                 (ONE all-to-all per step)
+    After the last step row ``j'_loc`` of R is the whole (L, M*M) matrix of that result row, and
+      I      ``out[j'_loc][i', (r,s)] = Ct[i', i] R[j'_loc][i, (r,s)]``
+    runs row by row INSIDE the buffer: result rows are packed from its start, received rows sit behind a gap of
+    one row (and of the growth ``(M - L) M^2`` per row when M > L), so the product of row p never reaches a
+    received row that is still to be read.  Every sum runs over the same index in the same order as in the
+    out-of-place layouts (d, c, the whole leading index, the sharded one): bit-identical results.
+
+    Peak memory: input rows + ``rows_buffer_elems`` (= result rows + one row when L = M) + 4 chunk_rows l^3.
+    ``out`` may supply the (flat) buffer to reuse it across steps of a time loop; the result is a view of it."""
+    Ct = _bra(C, C_tilde)
+    L, M = C.shape
+    ipart, jpart = (in_part or SlabPartition(L, world)), SlabPartition(M, world)
+    il, jl = ipart.count(rank), jpart.count(rank)
+    if tuple(rows.shape) != (il, L, L, L) or not rows.is_contiguous():
+        raise ValueError(f"rank {rank}: rows of shape {tuple(rows.shape)}, expected contiguous {(il, L, L, L)}")
+    dt = kernels.result_dtype(rows, C, Ct)
+    C, Ct = C.to(dt).contiguous(), Ct.to(dt).contiguous()
+    CT = C.transpose(0, 1).contiguous()
+    dev = rows.device
+    MM = M * M
+    width = 2 if dt.is_complex else 1
+    es = 16 if dt.is_complex else 8
+    nbuf = rows_buffer_elems(L, M, jl)
+    if out is None:
+        buf = torch.empty(nbuf, dtype=dt, device=dev)
+    else:
+        if out.dtype != dt or out.numel() < nbuf or not out.is_contiguous() or out.device != dev:
+            raise ValueError(f"`out` must be a contiguous {dt} buffer of at least {nbuf} elements")
+        buf = out.reshape(-1)
+    r0 = jl * max(M - L, 0) * MM + L * MM                  # element offset of received row 0
+    R = buf[r0: r0 + jl * L * MM].view(jl, L, MM)
+    il_max = max(ipart.count(g) for g in range(world))
+    ni = stream_chunk_rows(L, M, il_max, es) if chunk_rows is None else max(1, min(int(chunk_rows), il_max))
+    nsteps = -(-il_max // ni)
+    t1 = torch.empty(ni * L * L * M, dtype=dt, device=dev)
+    t2 = torch.empty(ni * L * MM, dtype=dt, device=dev)
+    W = torch.empty(M * ni * MM, dtype=dt, device=dev)
+    stage = None
+    if world > 1:
+        stage = torch.empty(jl * sum(min(ni, ipart.count(g)) for g in range(world)) * MM * width,
+                            dtype=torch.float64, device=dev)
+    for t in range(nsteps):
+        i0 = t * ni
+        n = max(0, min(ni, il - i0))
+        if n > 0:
+            src = rows[i0:i0 + n]
+            if src.dtype != dt:
+                src = src.to(dt)                           # (real u, complex C: cast chunk-wise, never the slab)
+            # d:  t1[(i,j,c), s] = rows[(i,j,c), d] C[d, s]
+            engine.gemm_strided(dt, src, C, t1, n * L * L, M, L, L, M, M)
+            # c:  t2[(i,j)][r, s] = CT[r, c] t1[(i,j)][c, s]
+            engine.gemm_strided(dt, CT, t1, t2, M, M, L, L, M, M, batch=n * L, sa=0, sb=L * M, sc=MM)
+            # J:  W[j', i, (r,s)] = Ct[j', j] t2[i][j, (r,s)]      one product per row i, rows of W n*MM apart
+            engine.gemm_strided(dt, Ct, t2, W, M, MM, L, L, MM, n * MM, batch=n, sa=0, sb=L * MM, sc=MM)
+        counts = [max(0, min(ni, ipart.count(g) - i0)) for g in range(world)]   # rows every rank brings to this step
+        if world == 1:
+            if n > 0:
+                R[:, i0:i0 + n].copy_(W[:M * n * MM].view(M, n, MM))
+            continue
+        in_splits = [jpart.count(g) * n * MM * width for g in range(world)]
+        out_splits = [jl * counts[g] * MM * width for g in range(world)]
+        recv = stage[:sum(out_splits)]
+        dist.all_to_all_single(recv, _as_real_flat(W[:M * n * MM]), out_splits, in_splits, group=group)
+        off = 0
+        for g in range(world):
+            if out_splits[g]:
+                blk = recv[off: off + out_splits[g]]
+                if width == 2:
+                    blk = torch.view_as_complex(blk.reshape(-1, 2))
+                g0 = ipart.starts[g] + i0
+                R[:, g0:g0 + counts[g]].copy_(blk.reshape(jl, counts[g], MM))
+            off += out_splits[g]
+    del t1, t2, W, stage
+    # I:  out[p][i', (r,s)] = Ct[i', i] R[p][i, (r,s)], packed from the start of the buffer
+    for p in range(jl):
+        engine.gemm_strided(dt, Ct, buf, buf, M, MM, L, L, MM, MM, b_off=r0 + p * L * MM, c_off=p * M * MM)
+    return buf[:jl * M * MM].view(jl, M, M, M)
+
+
+# ---------------------------------------------------------------------------
 # First consumers of a p-sharded u: Fock matrix and reference energy
 # (SURVEY 8f #2).  Every term needs u[p, ...] for ONE leading index p, so each
 # rank works on its slab and the node exchanges l*l (Fock rows) or one number

@@ -29,17 +29,18 @@ def _plain(t):
 
 
 def transform_two_body(t, C, Ct, np):
-    """Four-index transform of a sharded tensor: one all-to-all; the sharded index flips
-    (leading -> second: ``transform_two_body_sharded_a``; second -> leading:
-    ``transform_two_body_sharded``)."""
+    """Four-index transform of a sharded tensor: rows of one leading index in, rows of the other one out (the
+    sharded index flips), one all-to-all per streamed chunk of rows; per rank never more than the input rows, the
+    result rows and O(l^3) of scratch (``sharded.transform_two_body_rows``; on RCCL the whole pipeline is ONE C-ABI
+    call with the exchange overlapped on a second stream, ``ShardedDeviceModule.rccl``)."""
     M = C.shape[1]
-    if t.axis == 0:
-        local = sharded.transform_two_body_sharded_a(t.local, C, Ct, t.rank, t.world, t.group, engine=np.engine,
-                                                     in_part=t.part)
-        return ShardedTensor4(local, M, 1, t.rank, t.world, t.group)       # result: balanced split of M
-    local = sharded.transform_two_body_sharded(t.local, C, Ct, t.rank, t.world, t.group, engine=np.engine,
+    comm = np.rccl() if hasattr(np, "rccl") else None
+    if comm is not None:
+        rows = comm.transform_two_body_rows(t.rows, C, Ct, in_part=t.part)
+    else:
+        rows = sharded.transform_two_body_rows(t.rows, C, Ct, t.rank, t.world, t.group, engine=np.engine,
                                                in_part=t.part)
-    return ShardedTensor4(local, M, 0, t.rank, t.world, t.group)
+    return ShardedTensor4(None, M, 1 - t.axis, t.rank, t.world, t.group, rows=rows)   # balanced split of M
 
 
 def change_basis(bs, C, C_tilde=None):
@@ -88,14 +89,14 @@ def anti_symmetrize_two_body_elements(bs):
         return
     eng = bs.np.engine
     u = bs._u
-    bs.u = u._like(eng.antisymmetrize(u.local))
+    bs.u = u._like(eng.antisymmetrize(u.rows))
     if bs._spin_2_tb_recipe_valid():
         stack, _ = bs._spin_2_tb_recipe
         bs._spin_2_tb_recipe = (stack, True)
         bs._spin_2_tb = None                                     # rebuilt anti-symmetrised on the next access
     elif bs._spin_2_tb is not None:
         t = bs._spin_2_tb
-        bs.spin_2_tb = t._like(eng.antisymmetrize(t.local))
+        bs.spin_2_tb = t._like(eng.antisymmetrize(t.rows))
     bs._anti_symmetrized_u = True
 
 
@@ -110,7 +111,7 @@ def spin_2_tb_rows(bs):
         rows = np.engine.spin_squared_two_body(S, antisymmetrize=anti, p_lo=lo, p_hi=hi)
     else:
         rows = torch.empty((0, n, n, n), dtype=_C128, device=S.device)
-    return ShardedTensor4(rows, n, 0, np.rank, np.world, np.group)
+    return ShardedTensor4(None, n, 0, np.rank, np.world, np.group, rows=rows)
 
 
 def change_to_general_orbital_basis(bs, a=[1, 0], b=[0, 1], anti_symmetrize=True):
@@ -132,13 +133,17 @@ def change_to_general_orbital_basis(bs, a=[1, 0], b=[0, 1], anti_symmetrize=True
     anti_now = bool(anti_symmetrize) and not bs._anti_symmetrized_u
     old = bs._u if is_sharded(bs._u) else np.shard(bs._u)
     bs._u = None
-    if old.local.numel():
-        block = eng.spin_expand_block(old.local, antisymmetrize=anti_now, out_dtype=_C128)
+    if old.axis == 1:
+        # the doubling ties the FIRST index to the third and the second to the fourth: expand leading-index rows
+        # (one all-to-all of the spatial tensor, 1/16 of what is built from it)
+        old = old.reshard(0)
+    if old.rows.numel():
+        block = eng.spin_expand_block(old.rows, antisymmetrize=anti_now, out_dtype=_C128)
     else:
-        shape = tuple(2 * x for x in old.local.shape)
-        block = torch.empty(shape, dtype=_C128, device=old.local.device)
+        shape = tuple(2 * x for x in old.rows.shape)
+        block = torch.empty(shape, dtype=_C128, device=old.rows.device)
     # spin rows 2p, 2p+1 stay with the rank that holds spatial row p: the offsets double
-    new_u = ShardedTensor4(block, bs.l, old.axis, old.rank, old.world, old.group, old.part.doubled())
+    new_u = ShardedTensor4(None, bs.l, 0, old.rank, old.world, old.group, old.part.doubled(), rows=block)
     del old, block
 
     bs.h = wrap(d_h)
