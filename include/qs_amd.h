@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define QS_ABI_VERSION 2
+#define QS_ABI_VERSION 3
 
 enum {
     QS_OK = 0,
@@ -96,6 +96,21 @@ int qs_transform_two_body(int dtype, const void* u, const void* C,
                           const void* Ct, void* out, void* work,
                           int64_t work_bytes, int64_t L, int64_t M,
                           void* stream);
+
+/*
+ * The same transform for a REAL fp64 tensor against complex128 coefficients
+ * (NumPy's promotion at basis_set.py:341-342; the per-step call of a
+ * time-dependent solver on a real quantum-dot `u`, system.py:222-225):
+ *   u_f64 (L,L,L,L) fp64;  C (L,M), Ct (M,L), out (M,M,M,M) complex128.
+ * No complex copy of `u` is made: the d contraction reads the real tensor
+ * (8 bytes per element) and runs on the real matrix instruction against C seen
+ * as an (L, 2M) real matrix -- half the MFMA work of the promoted product --
+ * and the c, b, a contractions are complex.  Workspace:
+ * qs_transform_two_body_workspace(QS_C128, L, M).
+ */
+int qs_transform_two_body_mixed(const void* u_f64, const void* C, const void* Ct,
+                                void* out, void* work, int64_t work_bytes,
+                                int64_t L, int64_t M, void* stream);
 
 /*
  * The same transform IN PLACE, for a caller that drops the old tensor anyway
@@ -239,11 +254,22 @@ int qs_tdho_coulomb_elements_nm(void* out, const void* nm_table, int64_t l,
 int qs_comm_unique_id(void* id /* QS_UNIQUE_ID_BYTES */);
 int qs_comm_init(void** comm, int rank, int world, const void* unique_id);
 int qs_comm_destroy(void* comm);
+/* Tear down without waiting for outstanding operations (ncclCommAbort): the
+ * only thing left to do after a sharded call returned an error in the middle
+ * of its exchange (the handle then refuses further work: peers may be blocked
+ * in a group this rank never completed) or when a peer died. */
+int qs_comm_abort(void* comm);
 int qs_comm_rank(void* comm);
 int qs_comm_world(void* comm);
 const char* qs_last_comm_error(void);
 
 /*
+ * STATUS of the sharded entry points below: EXPERIMENTAL.  They have run on
+ * hardware with ONE rank only (the development boxes hold one GPU); worlds of
+ * 2..8 ranks are covered by CPU replays of their exchange plans
+ * (qs_sharded_exchange_plan, qs_sharded_rows_exchange_plan) and by the same
+ * algorithms driven through torch.distributed in the Python layer.
+ *
  * Four-index transform of a tensor sharded over the ranks of `comm`:
  *   u_bslab   : u[:, b_lo:b_hi, :, :]  (L, bl, L, L), this rank's share of the
  *               SECOND index; balanced split: the first L % world ranks hold
@@ -283,6 +309,58 @@ int qs_transform_two_body_sharded(void* comm, int dtype, const void* u_bslab,
 int qs_sharded_exchange_plan(int64_t L, int64_t M, int world, int rank,
                              int nchunks, int64_t* header, int64_t* ct_rows,
                              int64_t* chunks, int64_t* table, int64_t table_rows);
+
+/*
+ * The memory-lean sharded transform: rows of ONE leading index in, rows of the
+ * OTHER one out, everything else O(chunk_rows * l^3).  Replaces
+ * transform_two_body_elements (basis_set.py:336-350) for the per-step call on
+ * a resident sharded `u` (system.py:222-225) and inside change_basis
+ * (basis_set.py:374-382) when two slabs are all a GPU can hold (l = 512
+ * complex128 on 8 GPUs: 128 GiB in + 128 GiB out per rank).
+ *   rows       : (il, L, L, L) of `in_dtype` -- rows[i][j] = u[i_lo + i, j]
+ *                for a leading-index sharding, u[j, i_lo + i] for a
+ *                second-index sharding (the transform is symmetric under
+ *                swapping its two leading index pairs, so one routine serves
+ *                both); `in_starts` (world + 1 offsets, 0 ... L) gives every
+ *                rank's first row, NULL = the balanced split.  in_dtype
+ *                QS_F64 with dtype QS_C128 is the mixed product above.
+ *   out_buffer : qs_transform_two_body_sharded_rows_out_bytes(); on return its
+ *                first jl * M^3 elements are out[j'_loc][i'][r][s], this
+ *                rank's rows j' (balanced split of M) of the other
+ *                transformed leading index.  The rest of the buffer held the
+ *                received rows: the closing contraction runs row by row
+ *                inside it, no second slab.
+ *   chunk_rows : input rows per exchange step (<= 0: qs_sharded_rows_default_chunk,
+ *                at least four steps within a fixed scratch budget).  Per step
+ *                d, c and the contraction over the whole leading index run on
+ *                `stream`; the grouped ncclSend / ncclRecv of the step (one
+ *                contiguous message per peer and result row, landing in
+ *                place) run on the communicator's stream under the next
+ *                step's products.
+ * Collective: every rank passes the same L, M, chunk_rows, in_starts.
+ */
+int64_t qs_sharded_rows_default_chunk(int dtype, int64_t L, int64_t M, int world,
+                                      const int64_t* in_starts);
+int64_t qs_transform_two_body_sharded_rows_out_bytes(int dtype, int64_t L, int64_t M,
+                                                     int world, int rank);
+int64_t qs_transform_two_body_sharded_rows_workspace(int dtype, int64_t L, int64_t M,
+                                                     int64_t chunk_rows);
+int qs_transform_two_body_sharded_rows(void* comm, int in_dtype, int dtype,
+                                       const void* rows, const int64_t* in_starts,
+                                       const void* C, const void* Ct,
+                                       void* out_buffer, int64_t out_bytes,
+                                       void* work, int64_t work_bytes, int64_t L,
+                                       int64_t M, int64_t chunk_rows, void* stream);
+/* Its exchange plan for one rank as numbers (test hook, no GPU, no RCCL):
+ *   header : {i_start, il, jl, il_max, r0, out_elems, chunk_rows, nsteps}
+ *   table  : {step, peer, kind, w_off, buf_off, count, rows} per operation,
+ *            kind 0 send (offset into the step's send block W[j'][i][(r,s)]),
+ *            1 receive (offset into out_buffer), 2 own rows (W -> out_buffer,
+ *            `rows` pieces of `count` elements, pitches n*M*M and L*M*M).
+ * Returns the number of operations (<= table_rows) or a negative QS_ERR_*. */
+int qs_sharded_rows_exchange_plan(int64_t L, int64_t M, int world, int rank,
+                                  const int64_t* in_starts, int64_t chunk_rows,
+                                  int64_t* header, int64_t* table, int64_t table_rows);
 
 /*
  * Which kernels the calling thread's most recent compute entry point launched,

@@ -29,6 +29,8 @@ SIGNATURES = {
     "qs_transform_two_body_workspace": (c_i64, [c_int, c_i64, c_i64]),
     "qs_transform_two_body": (
         c_int, [c_int, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_i64, c_i64, c_i64, c_ptr]),
+    "qs_transform_two_body_mixed": (
+        c_int, [c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_i64, c_i64, c_i64, c_ptr]),
     "qs_transform_two_body_inplace_workspace": (c_i64, [c_int, c_i64, c_i64]),
     "qs_transform_two_body_inplace": (
         c_int, [c_int, c_ptr, c_ptr, c_ptr, c_ptr, c_i64, c_i64, c_i64, c_ptr]),
@@ -49,6 +51,7 @@ SIGNATURES = {
     "qs_comm_unique_id": (c_int, [c_ptr]),
     "qs_comm_init": (c_int, [ctypes.POINTER(c_ptr), c_int, c_int, c_ptr]),
     "qs_comm_destroy": (c_int, [c_ptr]),
+    "qs_comm_abort": (c_int, [c_ptr]),
     "qs_comm_rank": (c_int, [c_ptr]),
     "qs_comm_world": (c_int, [c_ptr]),
     "qs_last_comm_error": (ctypes.c_char_p, []),
@@ -56,6 +59,12 @@ SIGNATURES = {
     "qs_transform_two_body_sharded": (
         c_int, [c_ptr, c_int, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_i64, c_i64, c_i64, c_int, c_ptr]),
     "qs_sharded_exchange_plan": (c_int, [c_i64, c_i64, c_int, c_int, c_int, c_ptr, c_ptr, c_ptr, c_ptr, c_i64]),
+    "qs_sharded_rows_default_chunk": (c_i64, [c_int, c_i64, c_i64, c_int, c_ptr]),
+    "qs_transform_two_body_sharded_rows_out_bytes": (c_i64, [c_int, c_i64, c_i64, c_int, c_int]),
+    "qs_transform_two_body_sharded_rows_workspace": (c_i64, [c_int, c_i64, c_i64, c_i64]),
+    "qs_transform_two_body_sharded_rows": (
+        c_int, [c_ptr, c_int, c_int, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_i64, c_ptr, c_i64, c_i64, c_i64, c_i64, c_ptr]),
+    "qs_sharded_rows_exchange_plan": (c_int, [c_i64, c_i64, c_int, c_int, c_ptr, c_i64, c_ptr, c_ptr, c_i64]),
     "qs_last_dispatch": (ctypes.c_char_p, []),
     "qs_tuning_set": (c_int, [ctypes.c_char_p, c_i64]),
     "qs_tuning_reset": (c_int, []),
@@ -63,7 +72,7 @@ SIGNATURES = {
     "qs_probe_stream_copy": (c_int, [c_ptr, c_ptr, c_i64, c_ptr]),
 }
 
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 
 class QsLibraryError(RuntimeError):

@@ -127,6 +127,19 @@ static int gemm(int dtype, const void* A, const void* B, void* C, int64_t m, int
                      sa, sb, sc, accumulate, s);
 }
 
+int matmul_real_by_complex(const void* A, const void* B, void* out, int64_t m, int64_t n, int64_t k, int64_t lda,
+                           int64_t ldb, int64_t ldc, hipStream_t stream) {
+    return gemm_f64((const double*)A, (const double*)B, (double*)out, m, 2 * n, k, lda, 2 * ldb, 2 * ldc, 1, 0, 0, 0, 0,
+                    stream);
+}
+
+// the d contraction: T1[(abc), s] = u[(abc), d] C[d, s]; `in_dtype` is the tensor's type, `dtype` that of C and T1
+static int gemm_d(int in_dtype, int dtype, const void* u, const void* C, void* T1, int64_t rows3, int64_t L, int64_t M,
+                  hipStream_t s) {
+    if (in_dtype == dtype) return gemm(dtype, u, C, T1, rows3, M, L, L, M, M, 1, 0, 0, 0, s);
+    return matmul_real_by_complex(u, C, T1, rows3, M, L, L, M, M, s);
+}
+
 static inline int64_t even_up(int64_t x) { return (x + 1) & ~int64_t(1); }
 
 // Extents for which every product keeps its n and grid inside 32 bits.
@@ -140,19 +153,19 @@ static inline char* at(void* base, int64_t elems, size_t es) { return (char*)bas
 
 // contractions d, c, b on `rows` leading-index rows.  `CT` is scratch for C^T: the c contraction of
 // the tiled path multiplies with it; the fused small-basis pass reads C itself and needs no transpose.
-static int contract_dcb(int dtype, const void* u, const void* C, void* CT, const void* Ct,
+static int contract_dcb(int in_dtype, int dtype, const void* u, const void* C, void* CT, const void* Ct,
                         void* T1, void* T2, void* T3, int64_t rows, int64_t L, int64_t M,
                         hipStream_t s) {
     // small bases: d and c in one pass over the tensor (each slab u[a, b] is contiguous):
     //   T2[ab] = C^T . u[ab] . C   on the 4-wide matrix instruction, else on the 16-wide one
     int rc = 1;
-    if (g_tune.sandwich == 1 || g_tune.sandwich == 2 || g_tune.sandwich == 4 || g_tune.sandwich == 5)
+    if (in_dtype == dtype && (g_tune.sandwich == 1 || g_tune.sandwich == 2 || g_tune.sandwich == 4 || g_tune.sandwich == 5))
         rc = sandwich4_try(dtype, u, T2, C, M, 1, C, 1, M, rows * L, L, M, L * L, L, 1, M * M, M, 1, s);
-    if (rc == 1) rc = slab_pair_try(dtype, u, C, T2, rows * L, L, M, s);
+    if (rc == 1 && in_dtype == dtype) rc = slab_pair_try(dtype, u, C, T2, rows * L, L, M, s);
     if (rc == 1) {
         rc = transpose_small(dtype, C, CT, L, M, s);
         if (rc) return rc;
-        rc = gemm(dtype, u, C, T1, rows * L * L, M, L, L, M, M, 1, 0, 0, 0, s);
+        rc = gemm_d(in_dtype, dtype, u, C, T1, rows * L * L, L, M, s);
         if (rc) return rc;
         rc = gemm(dtype, CT, T1, T2, M, M, L, L, M, M, rows * L, 0, L * M, M * M, s);
     }
@@ -245,14 +258,18 @@ int64_t qs_transform_two_body_workspace(int dtype, int64_t L, int64_t M) {
     return (even_up(L * M) + wa + wb) * (int64_t)elem_size(dtype);
 }
 
-int qs_transform_two_body(int dtype, const void* u, const void* C, const void* Ct, void* out,
-                          void* work, int64_t work_bytes, int64_t L, int64_t M, void* stream) {
+}  // extern "C"
+
+namespace qs {
+// qs_transform_two_body / qs_transform_two_body_mixed: `in_dtype` is the type of u, `dtype` that of C, Ct and out
+static int transform_two_body_impl(int in_dtype, int dtype, const void* u, const void* C, const void* Ct, void* out,
+                                   void* work, int64_t work_bytes, int64_t L, int64_t M, void* stream) {
     dispatch_reset();
-    if (!dtype_ok(dtype)) return QS_ERR_BAD_DTYPE;
+    if (!dtype_ok(dtype) || !dtype_ok(in_dtype) || (in_dtype == QS_C128 && dtype == QS_F64)) return QS_ERR_BAD_DTYPE;
     if (!extents_ok(L, M)) return QS_ERR_BAD_EXTENT;
     if (!u || !C || !Ct || !out || !work) return QS_ERR_NULL_POINTER;
     const size_t es = elem_size(dtype);
-    if (!aligned(u, es) || !aligned(C, es) || !aligned(Ct, es) || !aligned(out, es) ||
+    if (!aligned(u, elem_size(in_dtype)) || !aligned(C, es) || !aligned(Ct, es) || !aligned(out, es) ||
         !aligned(work, 16))
         return QS_ERR_MISALIGNED;
     if (out == u || out == work) return QS_ERR_ALIAS;
@@ -266,7 +283,7 @@ int qs_transform_two_body(int dtype, const void* u, const void* C, const void* C
 
     // small bases: two passes over the tensor instead of four -- (d, c) per slab u[a, b], then (b, a) per
     // column (r, s): out[:, :, rs] = Ct . T2[:, :, rs] . Ct^T (the same k-ordered sums, element for element)
-    if (g_tune.sandwich == 1 || g_tune.sandwich == 3 || g_tune.sandwich == 4 || g_tune.sandwich == 6) {
+    if (in_dtype == dtype && (g_tune.sandwich == 1 || g_tune.sandwich == 3 || g_tune.sandwich == 4 || g_tune.sandwich == 6)) {
         // T2 (L, L, M, M) goes to WA; the eligibility of the second pass is known before the first runs
         const int64_t MM = M * M;
         const int64_t n4 = cdiv(L, 4);
@@ -326,9 +343,25 @@ int qs_transform_two_body(int dtype, const void* u, const void* C, const void* C
         }
     }
 
-    int rc = contract_dcb(dtype, u, C, CT, Ct, /*T1*/ WA, /*T2*/ WB, /*T3*/ WA, L, L, M, s);
+    int rc = contract_dcb(in_dtype, dtype, u, C, CT, Ct, /*T1*/ WA, /*T2*/ WB, /*T3*/ WA, L, L, M, s);
     if (rc) return rc;
     return gemm(dtype, Ct, WA, out, M, M * M * M, L, L, M * M * M, M * M * M, 1, 0, 0, 0, s);
+}
+}  // namespace qs
+
+extern "C" {
+
+int qs_transform_two_body(int dtype, const void* u, const void* C, const void* Ct, void* out,
+                          void* work, int64_t work_bytes, int64_t L, int64_t M, void* stream) {
+    return transform_two_body_impl(dtype, dtype, u, C, Ct, out, work, work_bytes, L, M, stream);
+}
+
+/* real fp64 u against complex128 coefficients -> complex128 result, without a complex copy of u: the d contraction
+ * reads the real tensor (8 bytes per element) and runs as a real product against C seen as an (L, 2M) real matrix; the
+ * other three contractions are complex.  Workspace: qs_transform_two_body_workspace(QS_C128, L, M). */
+int qs_transform_two_body_mixed(const void* u_f64, const void* C, const void* Ct, void* out, void* work,
+                                int64_t work_bytes, int64_t L, int64_t M, void* stream) {
+    return transform_two_body_impl(QS_F64, QS_C128, u_f64, C, Ct, out, work, work_bytes, L, M, stream);
 }
 
 int64_t qs_transform_two_body_inplace_workspace(int dtype, int64_t L, int64_t M) {
@@ -387,7 +420,7 @@ int qs_transform_two_body_partial(int dtype, const void* u_slab, const void* C, 
     void* CT = work;
     void* T1 = at(work, even_up(L * M), es);
     void* T2 = at(T1, rows * L * L * M, es);
-    return contract_dcb(dtype, u_slab, C, CT, Ct, T1, T2, v_slab, rows, L, M, s);
+    return contract_dcb(dtype, dtype, u_slab, C, CT, Ct, T1, T2, v_slab, rows, L, M, s);
 }
 
 int qs_transform_one_body(int dtype, const void* h, const void* C, const void* Ct, void* out,

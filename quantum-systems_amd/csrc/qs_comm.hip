@@ -24,6 +24,9 @@
 #include <stdio.h>
 #include <string.h>
 
+#include <memory>
+#include <new>
+
 #include "qs_common.h"
 
 namespace qs {
@@ -36,6 +39,7 @@ struct NcclUniqueId { char internal[QS_UNIQUE_ID_BYTES]; };
 typedef int (*fn_get_unique_id)(NcclUniqueId*);
 typedef int (*fn_comm_init_rank)(nccl_comm_t*, int, NcclUniqueId, int);
 typedef int (*fn_comm_destroy)(nccl_comm_t);
+typedef int (*fn_comm_abort)(nccl_comm_t);
 typedef int (*fn_group)(void);
 typedef int (*fn_send)(const void*, size_t, int, int, nccl_comm_t, hipStream_t);
 typedef int (*fn_recv)(void*, size_t, int, int, nccl_comm_t, hipStream_t);
@@ -47,6 +51,7 @@ struct Rccl {
     fn_get_unique_id get_unique_id = nullptr;
     fn_comm_init_rank comm_init_rank = nullptr;
     fn_comm_destroy comm_destroy = nullptr;
+    fn_comm_abort comm_abort = nullptr;      // optional
     fn_group group_start = nullptr, group_end = nullptr;
     fn_send send = nullptr;
     fn_recv recv = nullptr;
@@ -72,6 +77,7 @@ const Rccl& rccl() {
         r.get_unique_id = (fn_get_unique_id)dlsym(r.handle, "ncclGetUniqueId");
         r.comm_init_rank = (fn_comm_init_rank)dlsym(r.handle, "ncclCommInitRank");
         r.comm_destroy = (fn_comm_destroy)dlsym(r.handle, "ncclCommDestroy");
+        r.comm_abort = (fn_comm_abort)dlsym(r.handle, "ncclCommAbort");
         r.group_start = (fn_group)dlsym(r.handle, "ncclGroupStart");
         r.group_end = (fn_group)dlsym(r.handle, "ncclGroupEnd");
         r.send = (fn_send)dlsym(r.handle, "ncclSend");
@@ -166,7 +172,18 @@ struct Comm {
     int rank = 0, world = 1, device = 0;
     hipStream_t stream = nullptr;              // the exchange runs here, beside the caller's stream
     hipEvent_t x_ready[kMaxChunks], r_ready[kMaxChunks], idle, done;
+    std::unique_ptr<Plan> plan;                // exchange plan of the most recent call (1.5 MB: on the heap, per handle)
+    bool broken = false;                       // a call failed after its exchange had started: peers may be waiting in a
+                                               // group this rank never completed -- only qs_comm_abort / destroy are left
 };
+
+// A failure once send / receive operations of this call may have been posted: the peers can be blocked in a group that
+// this rank will never complete.  The handle is marked, so that every later call fails at once instead of dead-locking
+// too, and the caller tears the communicator down (qs_comm_abort).
+static int fail_mid_exchange(Comm* c, int rc) {
+    c->broken = true;
+    return rc;
+}
 
 }  // namespace qs
 
@@ -246,7 +263,9 @@ int qs_sharded_exchange_plan(int64_t L, int64_t M, int world, int rank, int nchu
     if (!header || !ct_rows || !chunks || !table) return QS_ERR_NULL_POINTER;
     if (nchunks < 1) nchunks = 4;
     if (nchunks > kMaxChunks) nchunks = kMaxChunks;
-    static thread_local Plan plan;
+    std::unique_ptr<Plan> holder(new (std::nothrow) Plan);
+    if (!holder) return QS_ERR_WORKSPACE;
+    Plan& plan = *holder;
     if (int rc = build_plan(plan, L, M, world, rank, nchunks)) return rc;
     if (plan.nops > table_rows) return QS_ERR_WORKSPACE;
     const int64_t h[7] = {plan.b_lo, plan.bl, plan.p_lo, plan.pc, plan.row_x, plan.row_r, nchunks};
@@ -264,6 +283,25 @@ int qs_sharded_exchange_plan(int64_t L, int64_t M, int world, int rank, int nchu
         memcpy(table + 7 * i, row, sizeof(row));
     }
     return plan.nops;
+}
+
+/* Tear a communicator down WITHOUT waiting for outstanding operations (ncclCommAbort): what is left to do after a call
+ * returned an error in the middle of its exchange, or when a peer died.  Frees the handle. */
+int qs_comm_abort(void* comm) {
+    if (!comm) return QS_ERR_NULL_POINTER;
+    Comm* c = (Comm*)comm;
+    int rc = QS_OK;
+    if (rccl().comm_abort) rc = rccl_status(rccl().comm_abort(c->nccl), "ncclCommAbort");
+    else rc = rccl_status(rccl().comm_destroy(c->nccl), "ncclCommDestroy");
+    for (int i = 0; i < kMaxChunks; ++i) {
+        (void)hipEventDestroy(c->x_ready[i]);
+        (void)hipEventDestroy(c->r_ready[i]);
+    }
+    (void)hipEventDestroy(c->idle);
+    (void)hipEventDestroy(c->done);
+    (void)hipStreamDestroy(c->stream);
+    delete c;
+    return rc;
 }
 
 int qs_comm_rank(void* comm) { return comm ? ((Comm*)comm)->rank : QS_ERR_NULL_POINTER; }
@@ -315,7 +353,13 @@ int qs_transform_two_body_sharded(void* comm, int dtype, const void* u_bslab, co
     void* R = at(T2, L * bl * MM);         // (pc, L, M*M): row p_loc, columns b of every sender
     void* X = T1;
 
-    static thread_local Plan plan;       // (large: not on the stack)
+    if (c->broken) {
+        snprintf(g_comm_err, sizeof(g_comm_err), "the communicator was left broken by an earlier failed call: abort / destroy it");
+        return QS_ERR_COMM;
+    }
+    if (!c->plan) c->plan.reset(new (std::nothrow) Plan);      // (large: neither on the stack nor in thread-local storage)
+    if (!c->plan) return QS_ERR_WORKSPACE;
+    Plan& plan = *c->plan;
     if (M > 1024) return QS_ERR_BAD_EXTENT;
     if (int prc = build_plan(plan, L, M, G, me, nchunks)) return prc;
     // ---- Ct rows in exchange order (device-to-device row copies on the caller's stream: runs of consecutive rows)
@@ -360,13 +404,16 @@ int qs_transform_two_body_sharded(void* comm, int dtype, const void* u_bslab, co
         if (bl > 0 && rows_k > 0) {
             rc = matmul_checked(dtype, at(CtX, slot0 * L), T2, at(X, slot0 * row_x), rows_k, row_x, L, L, row_x, row_x, 1, 0, 0,
                            0, 0, s);
-            if (rc) return rc;
+            if (rc) return k ? fail_mid_exchange(c, rc) : rc;
         }
         e = hipEventRecord(c->x_ready[k], s);
         if (e == hipSuccess) e = hipStreamWaitEvent(c->stream, c->x_ready[k], 0);
-        if (e != hipSuccess) return hip_status(e, "qs_transform_two_body_sharded: chunk ready");
+        if (e != hipSuccess) {
+            rc = hip_status(e, "qs_transform_two_body_sharded: chunk ready");
+            return k ? fail_mid_exchange(c, rc) : rc;
+        }
         // exchange of chunk k on the communicator's stream: one message per row and peer, all peers in one group
-        if (int grc = rccl_status(rccl().group_start(), "ncclGroupStart")) return grc;
+        if (int grc = rccl_status(rccl().group_start(), "ncclGroupStart")) return k ? fail_mid_exchange(c, grc) : grc;
         for (; op < plan.nops && plan.ops[op].chunk == k; ++op) {
             const PlanOp& o = plan.ops[op];
             int orc = QS_OK;
@@ -382,13 +429,13 @@ int qs_transform_two_body_sharded(void* comm, int dtype, const void* u_bslab, co
                 orc = rccl_status(rccl().recv(at(R, o.r_off), (size_t)(o.count * width), kNcclFloat64, o.peer, c->nccl,
                                               c->stream), "ncclRecv");
             }
-            if (orc) { rccl().group_end(); return orc; }
+            if (orc) { rccl().group_end(); return fail_mid_exchange(c, orc); }
         }
-        if (int grc = rccl_status(rccl().group_end(), "ncclGroupEnd")) return grc;
+        if (int grc = rccl_status(rccl().group_end(), "ncclGroupEnd")) return fail_mid_exchange(c, grc);
         e = hipEventRecord(c->r_ready[k], c->stream);
-        if (e != hipSuccess) return hip_status(e, "qs_transform_two_body_sharded: rows ready");
+        if (e != hipSuccess) return fail_mid_exchange(c, hip_status(e, "qs_transform_two_body_sharded: rows ready"));
         // while chunk k travels: close chunk k - 1 (its rows have arrived or are about to)
-        if (k > 0) { rc = close_chunk(k - 1); if (rc) return rc; }
+        if (k > 0) { rc = close_chunk(k - 1); if (rc) return fail_mid_exchange(c, rc); }
     }
     rc = close_chunk(nchunks - 1);
     if (rc) return rc;
@@ -397,6 +444,252 @@ int qs_transform_two_body_sharded(void* comm, int dtype, const void* u_bslab, co
     if (e == hipSuccess) e = hipStreamWaitEvent(s, c->done, 0);
     if (e != hipSuccess) return hip_status(e, "qs_transform_two_body_sharded: join");
     note_dispatch("rccl grouped send/recv (%d chunks)", nchunks);
+    return QS_OK;
+}
+
+}  // extern "C"
+
+// ------------------------------------------------------------------------------------------------------------------
+// Rows in, rows out: the memory-lean form (what sharded.transform_two_body_rows does with torch.distributed, as ONE
+// call on RCCL).  This rank holds rows[i][j][c][d], its rows i of ONE leading index of u with the other one whole
+// (u[a_lo + i, j] for a leading-index sharding, u[j, b_lo + i] for a second-index sharding: the transform is symmetric
+// under swapping its two leading index pairs), and gets the rows j' it owns of the OTHER transformed leading index,
+// out[j'_loc][i'][r][s].  Apart from those two only O(chunk_rows * l^3) exists at any time:
+//
+//   per step of chunk_rows input rows, on the caller's stream:
+//     d, c   t2[i][j][r, s] = C[c, r] rows[i][j][c, d] C[d, s]
+//     J      W[j', i, (r,s)] = Ct[j', j] t2[i][j, (r,s)]         W is stored [j'][i][(r,s)]: a peer's share is one block
+//   on the communicator's stream, overlapping the NEXT step's products (W is double-buffered):
+//     grouped ncclSend / ncclRecv, one message per (peer, j'): n*M*M contiguous elements on both sides -- no packing,
+//     no staging -- landing at R[j'_loc][i_global ...][(r,s)] inside the result buffer
+//   after the last step, on the caller's stream, row by row inside the result buffer:
+//     I      out[j'_loc][i', (r,s)] = Ct[i', i] R[j'_loc][i, (r,s)]
+//
+// Result rows are packed from the start of the buffer; received rows sit behind a gap of one row (plus the growth
+// (M - L) M^2 per row when M > L), so the product of row p never reaches a received row that is still to be read.
+// ------------------------------------------------------------------------------------------------------------------
+
+namespace qs {
+namespace {
+
+constexpr int64_t kRowsBudgetBytes = int64_t(8) << 30;      // scratch per rank (as sharded.STREAM_BUDGET_BYTES)
+
+struct RowsGeom {
+    int G, me;
+    int64_t L, M, MM, il, jl, il_max, i_start;      // my input rows [i_start, i_start + il), my result rows jl
+    int64_t r0;                                     // element offset of received row 0 in the result buffer
+    int64_t out_elems;
+};
+
+// start of rank g's input rows: the caller's table (world + 1 entries) or the balanced split
+inline int64_t in_lo(const int64_t* in_starts, int64_t L, int G, int g) { return in_starts ? in_starts[g] : part_lo(L, G, g); }
+
+int rows_geometry(RowsGeom& q, int64_t L, int64_t M, int G, int me, const int64_t* in_starts) {
+    if (L <= 0 || M <= 0 || L > 4096 || M > 1024 || G < 1 || me < 0 || me >= G) return QS_ERR_BAD_EXTENT;
+    if (in_starts) {
+        if (in_starts[0] != 0 || in_starts[G] != L) return QS_ERR_BAD_EXTENT;
+        for (int g = 0; g < G; ++g) if (in_starts[g + 1] < in_starts[g]) return QS_ERR_BAD_EXTENT;
+    }
+    q.G = G; q.me = me; q.L = L; q.M = M; q.MM = M * M;
+    q.i_start = in_lo(in_starts, L, G, me);
+    q.il = in_lo(in_starts, L, G, me + 1) - q.i_start;
+    q.jl = part_lo(M, G, me + 1) - part_lo(M, G, me);
+    q.il_max = 0;
+    for (int g = 0; g < G; ++g) {
+        const int64_t n = in_lo(in_starts, L, G, g + 1) - in_lo(in_starts, L, G, g);
+        if (n > q.il_max) q.il_max = n;
+    }
+    q.r0 = q.jl * (M > L ? M - L : 0) * q.MM + L * q.MM;
+    q.out_elems = q.jl * (M > L ? M : L) * q.MM + L * q.MM;
+    return QS_OK;
+}
+
+inline int64_t clamp_rows(int64_t have, int64_t i0, int64_t ni) {
+    const int64_t n = have - i0;
+    return n < 0 ? 0 : (n > ni ? ni : n);
+}
+
+// The operations of one step, in the order both sides of every pair post them (peer ascending; per peer the sends in
+// ascending j', the receives in ascending j'_loc).  kind 0 send (offset into W), 1 receive (offset into the result
+// buffer), 2 own rows (W -> buffer, `rows` pieces of `count` elements, pitches n*MM and L*MM).
+template <typename F>
+int rows_step_ops(const RowsGeom& q, const int64_t* in_starts, int64_t ni, int64_t step, F&& emit) {
+    const int64_t i0 = step * ni, n = clamp_rows(q.il, i0, ni), MM = q.MM;
+    for (int g = 0; g < q.G; ++g) {
+        const int64_t j_lo = part_lo(q.M, q.G, g), jc = part_lo(q.M, q.G, g + 1) - j_lo;
+        const int64_t g_start = in_lo(in_starts, q.L, q.G, g);
+        const int64_t ng = clamp_rows(in_lo(in_starts, q.L, q.G, g + 1) - g_start, i0, ni);   // rows rank g brings
+        if (g == q.me) {
+            if (n > 0 && q.jl > 0)
+                if (int rc = emit(PlanOp{(int)step, g, 2, j_lo * n * MM, q.r0 + (q.i_start + i0) * MM, n * MM, q.jl})) return rc;
+            continue;
+        }
+        for (int64_t j = 0; j < jc && n > 0; ++j)
+            if (int rc = emit(PlanOp{(int)step, g, 0, (j_lo + j) * n * MM, 0, n * MM, 1})) return rc;
+        for (int64_t j = 0; j < q.jl && ng > 0; ++j)
+            if (int rc = emit(PlanOp{(int)step, g, 1, 0, q.r0 + (j * q.L + g_start + i0) * MM, ng * MM, 1})) return rc;
+    }
+    return QS_OK;
+}
+
+inline int64_t rows_default_chunk(int64_t L, int64_t M, int64_t il_max, size_t es) {
+    int64_t unit = L * L * M;
+    if (L * M * M > unit) unit = L * M * M;
+    if (M * M * M > unit) unit = M * M * M;
+    int64_t ni = kRowsBudgetBytes / (5 * unit * (int64_t)es);
+    const int64_t quarter = (il_max + 3) / 4;          // at least four steps, so that the exchange has products to hide under
+    if (ni > quarter) ni = quarter;
+    return ni < 1 ? 1 : ni;
+}
+
+}  // namespace
+}  // namespace qs
+
+extern "C" {
+
+/* chunk_rows the library picks when the caller passes <= 0 (a function of the GLOBAL extents only: every rank gets
+ * the same number) */
+int64_t qs_sharded_rows_default_chunk(int dtype, int64_t L, int64_t M, int world, const int64_t* in_starts) {
+    if (!dtype_ok(dtype)) return QS_ERR_BAD_DTYPE;
+    RowsGeom q;
+    if (int rc = rows_geometry(q, L, M, world, 0, in_starts)) return rc;
+    return rows_default_chunk(L, M, q.il_max, elem_size(dtype));
+}
+
+/* bytes of the result buffer (the result rows are its first jl * M^3 elements) */
+int64_t qs_transform_two_body_sharded_rows_out_bytes(int dtype, int64_t L, int64_t M, int world, int rank) {
+    if (!dtype_ok(dtype)) return QS_ERR_BAD_DTYPE;
+    RowsGeom q;
+    if (int rc = rows_geometry(q, L, M, world, rank, nullptr)) return rc;
+    return q.out_elems * (int64_t)elem_size(dtype);
+}
+
+/* workspace: C^T | t1 | t2 | W0 | W1 */
+int64_t qs_transform_two_body_sharded_rows_workspace(int dtype, int64_t L, int64_t M, int64_t chunk_rows) {
+    if (!dtype_ok(dtype)) return QS_ERR_BAD_DTYPE;
+    if (L <= 0 || M <= 0 || L > 4096 || M > 1024 || chunk_rows < 1 || chunk_rows > L) return QS_ERR_BAD_EXTENT;
+    const int64_t lm = (L * M + 1) & ~int64_t(1), ni = chunk_rows, MM = M * M;
+    return (lm + ni * L * L * M + ni * L * MM + 2 * M * ni * MM + 8) * (int64_t)elem_size(dtype);
+}
+
+/* The exchange plan of one rank as numbers (no GPU, no RCCL): the CPU suite replays the plans of every rank of a world
+ * with NumPy.  header: {i_start, il, jl, il_max, r0, out_elems, chunk_rows, nsteps}; table: one row
+ * {step, peer, kind, w_off, buf_off, count, rows} per operation.  Returns the number of operations or an error. */
+int qs_sharded_rows_exchange_plan(int64_t L, int64_t M, int world, int rank, const int64_t* in_starts, int64_t chunk_rows,
+                                  int64_t* header, int64_t* table, int64_t table_rows) {
+    if (!header || !table) return QS_ERR_NULL_POINTER;
+    RowsGeom q;
+    if (int rc = rows_geometry(q, L, M, world, rank, in_starts)) return rc;
+    const int64_t ni = chunk_rows >= 1 ? (chunk_rows > q.il_max ? q.il_max : chunk_rows) : rows_default_chunk(L, M, q.il_max, 8);
+    const int64_t nsteps = (q.il_max + ni - 1) / ni;
+    const int64_t h[8] = {q.i_start, q.il, q.jl, q.il_max, q.r0, q.out_elems, ni, nsteps};
+    memcpy(header, h, sizeof(h));
+    int64_t nops = 0;
+    for (int64_t t = 0; t < nsteps; ++t) {
+        int rc = rows_step_ops(q, in_starts, ni, t, [&](const PlanOp& o) -> int {
+            if (nops >= table_rows) return QS_ERR_WORKSPACE;
+            const int64_t row[7] = {o.chunk, o.peer, o.kind, o.x_off, o.r_off, o.count, o.rows};
+            memcpy(table + 7 * nops, row, sizeof(row));
+            ++nops;
+            return QS_OK;
+        });
+        if (rc) return rc;
+    }
+    return (int)nops;
+}
+
+int qs_transform_two_body_sharded_rows(void* comm, int in_dtype, int dtype, const void* rows, const int64_t* in_starts,
+                                       const void* C, const void* Ct, void* out_buffer, int64_t out_bytes, void* work,
+                                       int64_t work_bytes, int64_t L, int64_t M, int64_t chunk_rows, void* stream) {
+    dispatch_reset();
+    if (!comm) return QS_ERR_NULL_POINTER;
+    Comm* c = (Comm*)comm;
+    if (!dtype_ok(dtype) || !dtype_ok(in_dtype) || (in_dtype == QS_C128 && dtype == QS_F64)) return QS_ERR_BAD_DTYPE;
+    RowsGeom q;
+    if (int rc = rows_geometry(q, L, M, c->world, c->rank, in_starts)) return rc;
+    if (!C || !Ct || !work || !out_buffer) return QS_ERR_NULL_POINTER;
+    if (q.il > 0 && !rows) return QS_ERR_NULL_POINTER;
+    const size_t es = elem_size(dtype), ies = elem_size(in_dtype);
+    if (!aligned(C, es) || !aligned(Ct, es) || !aligned(work, 16) || !aligned(out_buffer, 16) || (rows && !aligned(rows, ies)))
+        return QS_ERR_MISALIGNED;
+    if (out_buffer == rows || out_buffer == work) return QS_ERR_ALIAS;
+    const int64_t ni = chunk_rows >= 1 ? (chunk_rows > q.il_max ? q.il_max : chunk_rows)
+                                       : rows_default_chunk(L, M, q.il_max, es);
+    if (out_bytes < q.out_elems * (int64_t)es) return QS_ERR_WORKSPACE;
+    if (work_bytes < qs_transform_two_body_sharded_rows_workspace(dtype, L, M, ni)) return QS_ERR_WORKSPACE;
+    if (current_device() != c->device) return QS_ERR_BAD_EXTENT;      // the communicator belongs to another device
+    if (c->broken) {
+        snprintf(g_comm_err, sizeof(g_comm_err), "the communicator was left broken by an earlier failed call: abort / destroy it");
+        return QS_ERR_COMM;
+    }
+    hipStream_t s = (hipStream_t)stream;
+    const int64_t MM = q.MM, width = dtype == QS_C128 ? 2 : 1;
+    const int64_t nsteps = (q.il_max + ni - 1) / ni;
+    auto at = [&](void* base, int64_t elems) { return (void*)((char*)base + (size_t)elems * es); };
+    const int64_t lm = (L * M + 1) & ~int64_t(1);
+    void* CT = work;
+    void* T1 = at(CT, lm);
+    void* T2 = at(T1, ni * L * L * M);
+    void* W[2] = {at(T2, ni * L * MM), at(T2, ni * L * MM + M * ni * MM)};
+    bool posted = false;                                 // anything handed to RCCL yet?
+    auto fail = [&](int rc) { return posted ? fail_mid_exchange(c, rc) : rc; };
+
+    int rc = transpose_small(dtype, C, CT, L, M, s);
+    if (rc) return rc;
+    for (int64_t t = 0; t < nsteps; ++t) {
+        const int w = (int)(t & 1);
+        const int64_t i0 = t * ni, n = clamp_rows(q.il, i0, ni);
+        hipError_t e = hipSuccess;
+        // W[w] was last read by the exchange of step t - 2
+        if (t >= 2) e = hipStreamWaitEvent(s, c->r_ready[w], 0);
+        if (e != hipSuccess) return fail(hip_status(e, "qs_transform_two_body_sharded_rows: send buffer free"));
+        if (n > 0) {
+            const void* src = (const char*)rows + (size_t)(i0 * L * L * L) * ies;
+            // d:  t1[(i,j,c), s] = rows[(i,j,c), d] C[d, s]        (a real tensor against complex coefficients: the mixed product)
+            rc = in_dtype == dtype ? matmul_checked(dtype, src, C, T1, n * L * L, M, L, L, M, M, 1, 0, 0, 0, 0, s)
+                                   : matmul_real_by_complex(src, C, T1, n * L * L, M, L, L, M, M, s);
+            if (rc) return fail(rc);
+            // c:  t2[(i,j)][r, s] = CT[r, c] t1[(i,j)][c, s]
+            rc = matmul_checked(dtype, CT, T1, T2, M, M, L, L, M, M, n * L, 0, L * M, MM, 0, s);
+            if (rc) return fail(rc);
+            // J:  W[j', i, (r,s)] = Ct[j', j] t2[i][j, (r,s)]     one product per row i, rows of W n*MM apart
+            rc = matmul_checked(dtype, Ct, T2, W[w], M, MM, L, L, MM, n * MM, n, 0, L * MM, MM, 0, s);
+            if (rc) return fail(rc);
+        }
+        e = hipEventRecord(c->x_ready[w], s);
+        if (e == hipSuccess) e = hipStreamWaitEvent(c->stream, c->x_ready[w], 0);
+        if (e != hipSuccess) return fail(hip_status(e, "qs_transform_two_body_sharded_rows: chunk ready"));
+        if (int grc = rccl_status(rccl().group_start(), "ncclGroupStart")) return fail(grc);
+        posted = true;
+        rc = rows_step_ops(q, in_starts, ni, t, [&](const PlanOp& o) -> int {
+            if (o.kind == 2) {
+                hipError_t ce = hipMemcpy2DAsync(at(out_buffer, o.r_off), (size_t)(L * MM) * es, at(W[w], o.x_off),
+                                                 (size_t)o.count * es, (size_t)o.count * es, (size_t)o.rows,
+                                                 hipMemcpyDeviceToDevice, c->stream);
+                return ce == hipSuccess ? QS_OK : hip_status(ce, "qs_transform_two_body_sharded_rows: own rows");
+            }
+            if (o.kind == 0)
+                return rccl_status(rccl().send(at(W[w], o.x_off), (size_t)(o.count * width), kNcclFloat64, o.peer, c->nccl,
+                                               c->stream), "ncclSend");
+            return rccl_status(rccl().recv(at(out_buffer, o.r_off), (size_t)(o.count * width), kNcclFloat64, o.peer, c->nccl,
+                                           c->stream), "ncclRecv");
+        });
+        if (rc) { rccl().group_end(); return fail(rc); }
+        if (int grc = rccl_status(rccl().group_end(), "ncclGroupEnd")) return fail(grc);
+        e = hipEventRecord(c->r_ready[w], c->stream);
+        if (e != hipSuccess) return fail(hip_status(e, "qs_transform_two_body_sharded_rows: chunk sent"));
+    }
+    // every received row is complete only now: the closing products follow the whole exchange
+    hipError_t e = hipEventRecord(c->done, c->stream);
+    if (e == hipSuccess) e = hipStreamWaitEvent(s, c->done, 0);
+    if (e != hipSuccess) return fail(hip_status(e, "qs_transform_two_body_sharded_rows: join"));
+    // I:  out[p][i', (r,s)] = Ct[i', i] R[p][i, (r,s)], row by row, packed from the start of the buffer
+    for (int64_t p = 0; p < q.jl; ++p) {
+        rc = matmul_checked(dtype, Ct, at(out_buffer, q.r0 + p * L * MM), at(out_buffer, p * M * MM), M, MM, L, L, MM, MM, 1,
+                            0, 0, 0, 0, s);
+        if (rc) return rc;
+    }
+    note_dispatch("rccl grouped send/recv (%lld steps of %lld rows)", (long long)nsteps, (long long)ni);
     return QS_OK;
 }
 

@@ -84,6 +84,13 @@ int matmul_checked(int dtype, const void* A, const void* B, void* out, int64_t m
                    int64_t ldb, int64_t ldc, int64_t batch, int64_t stride_a, int64_t stride_b, int64_t stride_c,
                    int accumulate, hipStream_t stream);
 
+// A real (m x k, fp64) times B complex (k x n) -> out complex (m x n), row-major, leading dimensions in elements of each
+// operand's own type.  Interleaved complex storage makes this EXACTLY the real product A . [B as k x 2n] -> [out as
+// m x 2n]: the real kernels run it with 2 MFMAs per fragment pair and 8 bytes read per element of A -- no complex copy
+// of A (the d contraction of a real u against complex coefficients, basis_set.py:341-342 with NumPy's promotion).
+int matmul_real_by_complex(const void* A, const void* B, void* out, int64_t m, int64_t n, int64_t k, int64_t lda,
+                           int64_t ldb, int64_t ldc, hipStream_t stream);
+
 // VALU-free fast path, exact and edge forms (qs_gemm_fast.hip): QS_OK / error after launching, 1 = not eligible.
 int gemm_fast_try(int dtype, const double* A, const double* B, double* C, int64_t m, int64_t n,
                   int64_t k, int64_t lda, int64_t ldb, int64_t ldc, int64_t batch, int64_t sa,

@@ -165,6 +165,10 @@ class Workspace:
 
 workspace = Workspace()
 
+# A/B switch for measurements (bench.py --dtype mixed, tests): False restores the route of rounds 1-2 for a real u against
+# complex coefficients -- a complex copy of the whole tensor, then the complex transform.
+mixed_real_u = True
+
 
 @_plain
 def gemm_raw(dt, A, B, out, m, n, k, lda, ldb, ldc, batch=1, sa=0, sb=0, sc=0,
@@ -222,7 +226,10 @@ def transform_two_body(u, C, C_tilde=None, out=None):
     if C_tilde is None:
         C_tilde = default_bra(C)
     dt = result_dtype(u, C, C_tilde)
-    u = _dev(u, dt)
+    # a real fp64 tensor against complex coefficients (NumPy's promotion, basis_set.py:341-342; the time-propagation
+    # call on a real quantum-dot u) stays real: the d contraction reads it as it is (qs_transform_two_body_mixed)
+    mixed = dt == _C128 and isinstance(u, torch.Tensor) and u.dtype == _F64 and mixed_real_u
+    u = _dev(u, _F64 if mixed else dt)
     C = _dev(C, dt)
     Ct = _dev(C_tilde, dt)
     L, M = C.shape
@@ -238,13 +245,22 @@ def transform_two_body(u, C, C_tilde=None, out=None):
         _check_out(out, (M, M, M, M), dt, "transform_two_body")
     with _on_device_of(u, C, Ct, out):
         work = workspace.get(nbytes, u.device)
-        _ran(
-            lib.qs_transform_two_body(
-                code, u.data_ptr(), C.data_ptr(), Ct.data_ptr(), out.data_ptr(),
-                work.data_ptr(), work.numel(), L, M, _stream(),
-            ),
-            "qs_transform_two_body",
-        )
+        if mixed:
+            _ran(
+                lib.qs_transform_two_body_mixed(
+                    u.data_ptr(), C.data_ptr(), Ct.data_ptr(), out.data_ptr(),
+                    work.data_ptr(), work.numel(), L, M, _stream(),
+                ),
+                "qs_transform_two_body_mixed",
+            )
+        else:
+            _ran(
+                lib.qs_transform_two_body(
+                    code, u.data_ptr(), C.data_ptr(), Ct.data_ptr(), out.data_ptr(),
+                    work.data_ptr(), work.numel(), L, M, _stream(),
+                ),
+                "qs_transform_two_body",
+            )
     return out
 
 
@@ -609,12 +625,72 @@ class RcclComm:
             check(_lib.load().qs_comm_destroy(self._handle), "qs_comm_destroy")
             self._handle = None
 
+    def abort(self):
+        """Tear down without waiting for outstanding operations: after a call failed in the middle of its exchange."""
+        if self._handle:
+            handle, self._handle = self._handle, None
+            check(_lib.load().qs_comm_abort(handle), "qs_comm_abort")
+
     def __enter__(self):
         return self
 
     def __exit__(self, *exc):
         self.close()
         return False
+
+    @_plain
+    def transform_two_body_rows(self, rows, C, C_tilde=None, in_part=None, chunk_rows=0, out=None):
+        """Rows of one leading index of ``u`` in, rows of the other transformed leading index out, everything else
+        O(chunk_rows l^3): ``qs_transform_two_body_sharded_rows`` (see include/qs_amd.h and
+        ``sharded.transform_two_body_rows``, the same algorithm on torch.distributed).  ``rows`` (il, L, L, L) follows
+        ``in_part`` (a ``sharded.SlabPartition``; balanced by default); a real ``rows`` against complex coefficients
+        is not copied to complex.  Returns the (jl, M, M, M) view of the result buffer (``out`` may supply the flat
+        buffer to reuse it across the steps of a time loop)."""
+        import ctypes
+
+        lib = _lib.load()
+        if C_tilde is None:
+            C_tilde = default_bra(C)
+        dt = result_dtype(rows, C, C_tilde)
+        in_dt = _F64 if (dt == _C128 and rows.dtype == _F64 and mixed_real_u) else dt
+        rows, C, Ct = _dev(rows, in_dt), _dev(C, dt), _dev(C_tilde, dt)
+        L, M = C.shape
+        code = dtype_code(dt)
+        starts = None
+        if in_part is not None:
+            if (in_part.n, in_part.world) != (L, self.world):
+                raise ValueError("the input partition does not describe L rows over this communicator's ranks")
+            starts = (ctypes.c_int64 * (self.world + 1))(*in_part.starts)
+            il = in_part.count(self.rank)
+        else:
+            base, extra = divmod(L, self.world)
+            il = base + (1 if self.rank < extra else 0)
+        base, extra = divmod(M, self.world)
+        jl = base + (1 if self.rank < extra else 0)
+        if tuple(rows.shape) != (il, L, L, L) or tuple(Ct.shape) != (M, L):
+            raise ValueError(f"rank {self.rank}: expected rows of shape {(il, L, L, L)} and C_tilde {(M, L)}")
+        p_starts = ctypes.cast(starts, ctypes.c_void_p) if starts is not None else None
+        ni = int(chunk_rows)
+        if ni < 1:
+            ni = check(lib.qs_sharded_rows_default_chunk(code, L, M, self.world, p_starts), "chunk query")
+        es = 16 if dt == _C128 else 8
+        out_bytes = check(lib.qs_transform_two_body_sharded_rows_out_bytes(code, L, M, self.world, self.rank), "size query")
+        if out is None:
+            out = torch.empty(out_bytes // es, dtype=dt, device=rows.device)
+        elif (not isinstance(out, torch.Tensor) or out.dtype != dt or out.numel() * es < out_bytes
+              or not out.is_contiguous() or out.device != rows.device):
+            raise ValueError(f"`out` must be a contiguous {dt} buffer of at least {out_bytes // es} elements")
+        nbytes = check(lib.qs_transform_two_body_sharded_rows_workspace(code, L, M, ni), "workspace query")
+        with _on_device_of(rows, C, Ct, out):
+            work = workspace.get(nbytes, rows.device)
+            _ran(
+                lib.qs_transform_two_body_sharded_rows(
+                    self._handle, dtype_code(in_dt), code, rows.data_ptr(), p_starts, C.data_ptr(), Ct.data_ptr(),
+                    out.data_ptr(), out.numel() * es, work.data_ptr(), work.numel(), L, M, ni, _stream(),
+                ),
+                "qs_transform_two_body_sharded_rows",
+            )
+        return out.reshape(-1)[: jl * M * M * M].view(jl, M, M, M)
 
     def transform_two_body(self, u_bslab, C, C_tilde=None, out=None, nchunks=4):
         """``out[p_lo:p_hi]`` of the transform from ``u[:, b_lo:b_hi]`` (balanced splits): the whole sharded

@@ -40,7 +40,7 @@ class OracleEngine:
         # strided views over the flat storage, exactly the addressing qs_matmul uses
         def view(t, off, rows, cols, ld, stride):
             flat = t.reshape(-1)
-            return torch.as_strided(flat, (batch, rows, cols), (stride, ld, 1), storage_offset=off)
+            return torch.as_strided(flat, (batch, rows, cols), (stride, ld, 1), storage_offset=flat.storage_offset() + off)
 
         a = view(A, a_off, m, k, lda, sa).numpy()
         b = view(B, b_off, k, n, ldb, sb).numpy()
@@ -104,6 +104,39 @@ def main():
                     ub2, tC, tCt, rank, world, engine=OracleEngine, staging_rows=3, out=keep)
                 np.testing.assert_allclose(slab5.numpy(), ref[p_lo:p_hi], rtol=1e-12, atol=1e-12)
                 assert slab5.data_ptr() == keep.data_ptr()
+
+        # layout 4 (what ShardedDeviceModule uses): rows of one leading index in, rows of the other one out,
+        # streamed chunk by chunk -- both shardings, several chunk sizes, the buffer reused, the input untouched
+        j_lo, j_hi = sharded.SlabPartition(M, world).bounds(rank)
+        i_lo, i_hi = sharded.SlabPartition(L, world).bounds(rank)
+        for second in (False, True):
+            full_rows = tu.transpose(0, 1) if second else tu          # rows[i][j] = u[j, i] resp. u[i, j]
+            want = ref if second else ref.transpose(1, 0, 2, 3)       # out_rows[j'][i']
+            rows = full_rows[i_lo:i_hi].contiguous()
+            keep = None
+            for ni in (1, 2, None):
+                got = sharded.transform_two_body_rows(rows, tC, tCt, rank, world, engine=OracleEngine, chunk_rows=ni,
+                                                      out=keep)
+                np.testing.assert_allclose(got.numpy(), want[j_lo:j_hi], rtol=1e-12, atol=1e-12)
+                assert got.is_contiguous() and torch.equal(rows, full_rows[i_lo:i_hi])
+                if keep is None:
+                    keep = torch.empty(sharded.rows_buffer_elems(L, M, j_hi - j_lo), dtype=got.dtype)
+                else:
+                    assert got.data_ptr() == keep.data_ptr()
+        if not cplx:
+            # a real tensor against complex coefficients: cast chunk-wise, never as a whole
+            Cc = tC * (1 + 0.5j)
+            got = sharded.transform_two_body_rows(tu[i_lo:i_hi].contiguous(), Cc, None, rank, world, engine=OracleEngine,
+                                                  chunk_rows=1)
+            refc = orc.transform_two_body(u, Cc.numpy())
+            np.testing.assert_allclose(got.numpy(), refc.transpose(1, 0, 2, 3)[j_lo:j_hi], rtol=1e-12, atol=1e-12)
+        if L % 2 == 0 and L // 2 >= 1:
+            # the partition spin doubling leaves behind (twice the offsets of L/2 spatial rows)
+            part = sharded.SlabPartition(L // 2, world).doubled()
+            d_lo, d_hi = part.bounds(rank)
+            got = sharded.transform_two_body_rows(tu[d_lo:d_hi].contiguous(), tC, tCt, rank, world, engine=OracleEngine,
+                                                  in_part=part, chunk_rows=2)
+            np.testing.assert_allclose(got.numpy(), ref.transpose(1, 0, 2, 3)[j_lo:j_hi], rtol=1e-12, atol=1e-12)
 
         # default bra (C^dagger) path
         slab3 = sharded.transform_two_body_sharded(ub, tC, None, rank, world, engine=OracleEngine)

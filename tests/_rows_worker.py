@@ -1,0 +1,91 @@
+"""Worker for tests/test_gpu_sharded_rows.py (torch.distributed.run, gloo carrying the collectives, the HIP engine,
+every rank on cuda:0 -- the one-device rehearsal of a node): the streamed rows-in / rows-out transform behind the
+sharded array module against the oracle, bit-for-bit against the out-of-place layouts of rounds 1-2, and within its
+memory bound: input rows + result rows + 2 rows + c l^3 per rank."""
+
+import os
+import sys
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+from oracle import qs_oracle as orc  # noqa: E402
+import quantum_systems_amd as qsa  # noqa: E402
+from quantum_systems_amd import kernels as K, sharded  # noqa: E402
+
+
+def main():
+    dist.init_process_group("gloo")
+    rank, world = dist.get_rank(), dist.get_world_size()
+    torch.cuda.set_device(0)
+    dev = torch.device("cuda:0")
+    rng = np.random.default_rng(7)                      # the same stream on every rank
+    for (L, M, cplx) in ((12, 12, False), (18, 18, True), (14, 9, True), (9, 14, False), (66, 66, False)):
+        u = rng.standard_normal((L,) * 4)
+        C = rng.standard_normal((L, M)) / np.sqrt(L)
+        Ct = rng.standard_normal((M, L)) / np.sqrt(L)
+        if cplx:
+            u = u + 1j * rng.standard_normal((L,) * 4)
+            C = C + 1j * rng.standard_normal((L, M)) / np.sqrt(L)
+            Ct = Ct + 1j * rng.standard_normal((M, L)) / np.sqrt(L)
+        ref = orc.transform_two_body(u, C, Ct)
+        es = 16 if cplx else 8
+        dC, dCt = torch.from_numpy(C).to(dev), torch.from_numpy(Ct).to(dev)
+        i_lo, i_hi = sharded.SlabPartition(L, world).bounds(rank)
+        j_lo, j_hi = sharded.SlabPartition(M, world).bounds(rank)
+        # the out-of-place layouts of rounds 1-2 on the same numbers (what "bit-equal to today's layouts" refers to)
+        old_a = sharded.transform_two_body_sharded_a(torch.from_numpy(np.ascontiguousarray(u[i_lo:i_hi])).to(dev), dC, dCt,
+                                                     rank, world)                    # (M, ql, M, M) = out[:, q_lo:q_hi]
+        old_b = sharded.transform_two_body_sharded(torch.from_numpy(np.ascontiguousarray(u[:, i_lo:i_hi])).to(dev), dC, dCt,
+                                                   rank, world)                      # (pc, M, M, M) = out[p_lo:p_hi]
+        for second in (False, True):
+            full_rows = u.transpose(1, 0, 2, 3) if second else u
+            want = ref if second else ref.transpose(1, 0, 2, 3)
+            rows = torch.from_numpy(np.ascontiguousarray(full_rows[i_lo:i_hi])).to(dev)
+            for ni in (1, 3, None):
+                K.workspace.release()
+                torch.cuda.synchronize()
+                torch.cuda.empty_cache()
+                torch.cuda.reset_peak_memory_stats()
+                base = torch.cuda.memory_allocated()
+                got = sharded.transform_two_body_rows(rows, dC, dCt, rank, world, chunk_rows=ni)
+                torch.cuda.synchronize()
+                peak = torch.cuda.max_memory_allocated() - base
+                n_eff = min(ni or 10**9, sharded.stream_chunk_rows(L, M, -(-L // world), es) if ni is None else ni,
+                            -(-L // world))
+                lmax = max(L, M)
+                bound = ((j_hi - j_lo) * lmax * M * M + 2 * lmax**3 + 5 * n_eff * lmax**3) * es + (1 << 20)
+                assert peak <= bound, (L, M, ni, peak, bound)
+                g = got.cpu().numpy()
+                assert np.abs(g - want[j_lo:j_hi]).max() <= 1e-10 * np.abs(ref).max(), (L, M, second, ni)
+                old = old_b if second else old_a.transpose(0, 1)
+                assert torch.equal(got, old), (L, M, second, ni)                     # the same sums in the same order
+                del got
+        del old_a, old_b
+    # ---- through the array module: ShardedTensor4 in, ShardedTensor4 out, the sharded index flips and flips back
+    mod = qsa.ShardedDeviceModule(rank, world, device="cuda:0")
+    assert mod.rccl() is None                          # gloo: the exchange goes through torch.distributed
+    L = 10
+    u = rng.standard_normal((L,) * 4) + 1j * rng.standard_normal((L,) * 4)
+    C = np.linalg.qr(rng.standard_normal((L, L)) + 1j * rng.standard_normal((L, L)))[0]
+    t = mod.shard(u)
+    one = qsa.BasisSet.transform_two_body_elements(t, mod.asarray(C), mod)
+    ref = orc.transform_two_body(u, C)
+    assert one.axis == 1 and tuple(one.rows.shape)[1:] == (L, L, L)
+    assert np.abs(one.local.cpu().numpy() - ref[:, one.lo:one.hi]).max() <= 1e-10 * np.abs(ref).max()
+    back = qsa.BasisSet.transform_two_body_elements(one, mod.asarray(C.conj().T.copy()), mod)
+    assert back.axis == 0
+    assert np.abs(back.local.cpu().numpy() - u[back.lo:back.hi]).max() <= 1e-9 * np.abs(u).max()      # unitary round trip
+    assert np.abs(one.gather().cpu().numpy() - ref).max() <= 1e-10 * np.abs(ref).max()
+    assert np.abs(one.reshard(0).local.cpu().numpy() - ref[one.reshard(0).lo:one.reshard(0).hi]).max() <= 1e-10 * np.abs(ref).max()
+    dist.barrier()
+    dist.destroy_process_group()
+    print(f"rank {rank}/{world} ok")
+
+
+if __name__ == "__main__":
+    main()

@@ -66,6 +66,55 @@ def test_transform_golden(K, golden, name):
     assert relerr(h, g["h_out"]) <= RTOL
 
 
+def test_mixed_real_u_complex_C_runs_without_a_complex_copy_of_u(K, golden):
+    # a real tensor against complex coefficients (NumPy's promotion, basis_set.py:341-342) goes through
+    # qs_transform_two_body_mixed -- the d contraction is a REAL product on the real tensor (C seen as an (L, 2M) real
+    # matrix), the rest complex -- instead of a complex copy of the whole tensor followed by the complex transform.
+    g = golden("transform_mixed_real_u_complex_C")
+    assert g["u"].dtype == np.float64 and g["C"].dtype == np.complex128
+    u, C = dev(g["u"]), dev(g["C"])
+    got = K.transform_two_body(u, C)
+    ran = K.last_dispatch().split(";")
+    first = [r for r in ran if "gemm" in r][0]
+    assert "<false" in first or "gemm_kernel<" in first or "stream_left_kernel" in first, ran     # the real product first
+    assert relerr(host(got), g["u_out"]) <= RTOL
+    K.mixed_real_u = False
+    try:
+        cast = K.transform_two_body(u, C)
+    finally:
+        K.mixed_real_u = True
+    assert (got - cast).abs().max().item() <= 1e-13 * cast.abs().max().item()
+    # oracle sweep through the new route: odd sizes, rectangular both ways, explicit C~, whole tiles, the fused sizes
+    rng = np.random.default_rng(33)
+    for (L, M) in ((5, 5), (9, 14), (21, 13), (40, 40), (64, 64), (55, 55), (70, 66), (128, 128)):
+        un = rng.standard_normal((L,) * 4)
+        Cn = (rng.standard_normal((L, M)) + 1j * rng.standard_normal((L, M))) / np.sqrt(L)
+        Ctn = (rng.standard_normal((M, L)) + 1j * rng.standard_normal((M, L))) / np.sqrt(L)
+        d_u = dev(un)
+        got = K.transform_two_body(d_u, dev(Cn), dev(Ctn))
+        assert got.dtype == torch.complex128
+        if L <= 70:
+            assert relerr(host(got), orc.transform_two_body(un, Cn, Ctn)) <= RTOL, (L, M)
+        else:
+            K.mixed_real_u = False
+            try:
+                cast = K.transform_two_body(d_u, dev(Cn), dev(Ctn))
+            finally:
+                K.mixed_real_u = True
+            assert (got - cast).abs().max().item() <= 1e-12 * cast.abs().max().item()
+        assert np.array_equal(host(d_u), un)                          # the real tensor is read, not converted
+    # argument checks of the entry point itself
+    from quantum_systems_amd import _lib
+    lib = _lib.load()
+    s0 = torch.cuda.current_stream().cuda_stream
+    w = torch.empty(lib.qs_transform_two_body_workspace(1, 4, 4), dtype=torch.uint8, device="cuda")
+    u4, C4 = dev(rng.standard_normal((4,) * 4)), dev(crand(rng, 4, 4))
+    o4 = torch.empty((4,) * 4, dtype=torch.complex128, device="cuda")
+    assert lib.qs_transform_two_body_mixed(u4.data_ptr(), C4.data_ptr(), C4.data_ptr(), o4.data_ptr(), w.data_ptr(), 16, 4, 4, s0) == -4
+    assert lib.qs_transform_two_body_mixed(None, C4.data_ptr(), C4.data_ptr(), o4.data_ptr(), w.data_ptr(), w.numel(), 4, 4, s0) == -2
+    assert lib.qs_transform_two_body_mixed(u4.data_ptr(), C4.data_ptr(), C4.data_ptr(), o4.data_ptr(), w.data_ptr(), w.numel(), 4, 4, s0) == 0
+
+
 def test_spf_golden(K, golden):
     g = golden("transform_spf")
     L = g["C"].shape[0]

@@ -88,3 +88,102 @@ def test_replayed_exchange_gives_the_transform(world, L, M, nchunks, cplx):
         rows = R[r].reshape(pl["pc"], L, MM)
         out = np.einsum("qb,pbn->pqn", Ct, rows).reshape(pl["pc"], M, M, M)
         np.testing.assert_allclose(out, ref[pl["p_lo"]:pl["p_lo"] + pl["pc"]], rtol=1e-11, atol=1e-11)
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# rows in, rows out (qs_transform_two_body_sharded_rows): the streamed, memory-lean form
+# ---------------------------------------------------------------------------------------------------------------
+
+
+def rows_plan_of(lib, L, M, world, rank, starts, chunk_rows):
+    header = (ctypes.c_int64 * 8)()
+    cap = 64 + 4 * (M + world) * (L + 1)
+    table = (ctypes.c_int64 * (7 * cap))()
+    p_starts = (ctypes.c_int64 * (world + 1))(*starts) if starts is not None else None
+    n = lib.qs_sharded_rows_exchange_plan(L, M, world, rank, p_starts, chunk_rows, header, table, cap)
+    assert n >= 0, n
+    keys = ("i_start", "il", "jl", "il_max", "r0", "out_elems", "chunk_rows", "nsteps")
+    pl = dict(zip(keys, (int(x) for x in header)))
+    pl["ops"] = np.array(table[: 7 * n], dtype=np.int64).reshape(n, 7)
+    return pl
+
+
+@pytest.mark.parametrize("world", [1, 2, 3, 8])
+@pytest.mark.parametrize("L,M,chunk_rows,cplx,doubled", [
+    (8, 8, 1, False, False), (9, 7, 2, True, False), (6, 10, 1, True, False), (12, 12, 3, False, False),
+    (10, 8, 2, True, True),         # the partition spin doubling leaves behind (twice the offsets of 5 spatial rows)
+    (11, 11, 0, False, False),      # chunk_rows <= 0: the library's own choice
+])
+@pytest.mark.parametrize("second_index", [False, True])
+def test_replayed_rows_exchange_gives_the_transform(world, L, M, chunk_rows, cplx, doubled, second_index):
+    # Replay of every rank's plan with NumPy: per step the three local products into the send block W[j'][i][(r,s)],
+    # the grouped sends / receives matched pairwise in issue order, the own-rows copy; after the last step the closing
+    # product row by row INSIDE the result buffer.  Checked: every rank's result rows against the oracle (both
+    # shardings: the routine is symmetric in the two leading indices), nothing read before it arrived, and the
+    # in-buffer product never overwriting a received row that is still to be read.
+    from quantum_systems_amd import _lib
+    from quantum_systems_amd.sharded import SlabPartition
+
+    lib = _lib.load()
+    rng = np.random.default_rng(L * 1000 + M * 10 + world)
+    u = rng.standard_normal((L,) * 4)
+    C = rng.standard_normal((L, M))
+    Ct = rng.standard_normal((M, L))
+    if cplx:
+        u = u + 1j * rng.standard_normal((L,) * 4)
+        C = C + 1j * rng.standard_normal((L, M))
+        Ct = Ct + 1j * rng.standard_normal((M, L))
+    ref = orc.transform_two_body(u, C, Ct)
+    MM = M * M
+    starts = SlabPartition(L // 2, world).doubled().starts if doubled else None
+    ipart = SlabPartition(L, world, starts)
+    jpart = SlabPartition(M, world)
+    plans = [rows_plan_of(lib, L, M, world, r, starts, chunk_rows) for r in range(world)]
+    ni, nsteps = plans[0]["chunk_rows"], plans[0]["nsteps"]
+    for r, pl in enumerate(plans):
+        assert (pl["i_start"], pl["i_start"] + pl["il"]) == ipart.bounds(r) and pl["jl"] == jpart.count(r)
+        assert (pl["chunk_rows"], pl["nsteps"]) == (ni, nsteps) and nsteps == -(-pl["il_max"] // ni)
+        assert pl["out_elems"] == pl["jl"] * max(L, M) * MM + L * MM
+    # rows[i][j] = u[i_lo + i, j] (leading-index sharding) or u[j, i_lo + i] (second-index sharding)
+    full_rows = u.transpose(1, 0, 2, 3) if second_index else u
+    want = ref.transpose(1, 0, 2, 3) if not second_index else ref          # out_rows[j'][i'] = out[i', j'] resp. out[j', i']
+    bufs = [np.full(pl["out_elems"], np.nan, dtype=ref.dtype) for pl in plans]
+    for t in range(nsteps):
+        Ws = []
+        for r, pl in enumerate(plans):
+            i0 = t * ni
+            n = max(0, min(ni, pl["il"] - i0))
+            rows = full_rows[pl["i_start"] + i0: pl["i_start"] + i0 + n]
+            t2 = np.einsum("ijcd,cr,ds->ijrs", rows, C, C)                  # d, c
+            W = np.einsum("kj,ijrs->kirs", Ct, t2)                          # J: W[j', i, r, s]
+            Ws.append(np.ascontiguousarray(W).reshape(-1))
+        sends, recvs = {}, {}
+        for r, pl in enumerate(plans):
+            n = max(0, min(ni, pl["il"] - t * ni))
+            for (step, peer, kind, w_off, b_off, count, nrows) in pl["ops"]:
+                if step != t:
+                    continue
+                if kind == 0:
+                    sends.setdefault((r, peer), []).append((w_off, count))
+                elif kind == 1:
+                    recvs.setdefault((peer, r), []).append((b_off, count))
+                else:
+                    assert peer == r and count == n * MM
+                    for i in range(nrows):
+                        bufs[r][b_off + i * L * MM: b_off + i * L * MM + count] = Ws[r][w_off + i * count: w_off + (i + 1) * count]
+        assert set(sends) == set(recvs)
+        for (src, dst), msgs in sends.items():
+            got = recvs[(src, dst)]
+            assert [c for (_, c) in msgs] == [c for (_, c) in got], (src, dst)
+            for (w_off, count), (b_off, _) in zip(msgs, got):
+                bufs[dst][b_off: b_off + count] = Ws[src][w_off: w_off + count]
+    for r, pl in enumerate(plans):
+        buf, r0, jl = bufs[r], pl["r0"], pl["jl"]
+        assert not np.isnan(buf[r0: r0 + jl * L * MM]).any()                # every received element was delivered
+        for p in range(jl):
+            row = buf[r0 + p * L * MM: r0 + (p + 1) * L * MM].reshape(L, MM).copy()
+            assert p * M * MM + M * MM <= r0 + p * L * MM                  # the product stops short of the row it reads ...
+            buf[p * M * MM: (p + 1) * M * MM] = (Ct @ row).reshape(-1)      # ... and of every later one
+        got = buf[: jl * M * MM].reshape(jl, M, M, M)
+        j_lo, j_hi = jpart.bounds(r)
+        np.testing.assert_allclose(got, want[j_lo:j_hi], rtol=1e-11, atol=1e-11)
