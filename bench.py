@@ -1,7 +1,7 @@
 """Headline benchmark: four-index transform of the two-body integrals.
 
-    python bench.py [--gpus N --steps K --warmup W] [--orbitals 256] [--dtype f64|c128]
-                    [--layout auto|replicated|sharded|inplace] [--gather] [--fresh-c auto|on|off]
+    python bench.py [--gpus N --steps K --warmup W] [--orbitals 256] [--dtype f64|c128|mixed] [--config 2|3|4]
+                    [--layout auto|replicated|rows|rows_rccl|sharded|inplace|rccl] [--gather] [--fresh-c auto|on|off]
                     [--workload transform|spin_expand|antisymmetrize] [--no-cpu-baseline]
 
 Metric (BASELINE.json): "4-index u transform TFLOP/s (fp64) at L orbitals".
@@ -25,10 +25,24 @@ over its leading index p.  Layouts:
               (l=512 complex128, 1.1 TB) needs; slabs are generated per rank;
   rccl        the sharded layout in ONE C-ABI call per step (qs_transform_two_body_sharded:
               RCCL driven directly, grouped send/recv per peer, chunked exchange on its own
-              stream overlapped with the products).
+              stream overlapped with the products);
+  rows        what ShardedDeviceModule does behind the API: rows of one leading index in,
+              rows of the other out, streamed (input rows + result rows + O(l^3) per GPU),
+              one all-to-all per chunk of rows through torch.distributed;
+  rows_rccl   the same as ONE C-ABI call (qs_transform_two_body_sharded_rows), the exchange
+              on the communicator's stream under the next chunk's products.
 The north star's single all-gather (replicating the p-sharded result) is timed
 as a second leg and reported next to the no-collective value; `--gather` makes
 it part of `value`.
+
+`--layout auto` at N > 1 (what the driver's one command runs) measures EVERY layout that
+fits, one after the other, each as its own group of fresh rank processes (a leg that fails or
+hangs is recorded and killed, the others stand): `legs` holds each leg's TFLOP/s, ms/step and
+parity; `value` is the best leg whose time INCLUDES a collective (replicated + all-gather of
+the result, or a sharded layout with its all-to-all), and `config.layout` names it.
+`--config 3` = BASELINE.json configs[3] (spin expansion l=256 -> 512), `--config 4` =
+configs[4] (l=512 complex128, slabs generated per rank, rows layout, a new C(t) per step;
+below 8 GPUs the largest l whose two slabs fit).
 
 Prints ONE JSON line on rank 0; exits non-zero if the parity property fails.
 """
@@ -46,7 +60,7 @@ sys.path.insert(0, ROOT)
 MFMA_F64_PEAK_TFLOPS = 78.6   # 256 CU x 4 SIMD x 2048 flop / 64 clk x 2.4 GHz (MI355X_MICROARCH.md clocks)
 HBM_PEAK_GBPS = 8000.0        # MI355X_MICROARCH.md: 8 TB/s spec (6.3 TB/s measured achievable)
 PARITY_BOUND = 1e-10          # BASELINE.json north_star: <= 1e-10 relative fp64
-HBM_BYTES = 288e9
+HBM_BYTES = 288 * 2**30      # hipMemGetInfo on the box: 309.2e9 bytes
 
 
 def parse(argv=None):
@@ -56,8 +70,21 @@ def parse(argv=None):
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--orbitals", "-l", dest="l", type=int, default=256,
                     help="number of orbitals l (named so that torch.distributed.run does not read it as --l*)")
-    ap.add_argument("--dtype", choices=["f64", "c128"], default="f64")
-    ap.add_argument("--layout", choices=["auto", "replicated", "sharded", "inplace", "rccl"], default="auto")
+    ap.add_argument("--dtype", choices=["f64", "c128", "mixed"], default="f64",
+                    help="mixed = real fp64 u against complex128 coefficients (the time-propagation call on a real "
+                         "quantum-dot u): complex128 result")
+    ap.add_argument("--mixed-route", choices=["native", "cast"], default="native",
+                    help="native: the real tensor is read as it is (qs_transform_two_body_mixed); cast: rounds 1-2, a "
+                         "complex copy of the tensor first (A/B)")
+    ap.add_argument("--layout", choices=["auto", "replicated", "sharded", "inplace", "rccl", "rows", "rows_rccl"],
+                    default="auto")
+    ap.add_argument("--config", type=int, choices=[2, 3, 4], default=None,
+                    help="preset: BASELINE.json configs[2] (default), [3] spin expansion l=256 -> 512, "
+                         "[4] l=512 complex128 time-evolution pattern on per-rank slabs")
+    ap.add_argument("--legs", default="replicated,rows,rows_rccl,rccl",
+                    help="layouts measured by --layout auto at N > 1, in this order")
+    ap.add_argument("--leg-timeout", type=float, default=420.0, help="seconds before a leg is given up and killed")
+    ap.add_argument("--chunk-rows", type=int, default=0, help="input rows per exchange step of the rows layouts (0 = automatic)")
     ap.add_argument("--gather", action="store_true", help="make the all-gather of the result part of `value`")
     ap.add_argument("--no-gather-leg", action="store_true", help="skip the second, gather-inclusive timing leg at N > 1")
     ap.add_argument("--fresh-c", choices=["auto", "on", "off"], default="auto",
@@ -78,10 +105,11 @@ def parse(argv=None):
 # self-launch: `python bench.py --gpus N` without an external launcher
 # ----------------------------------------------------------------------------------------------
 
-def self_launch(n):
-    """Start the N rank processes (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* in their environment, as
-    torch.distributed.run would set them), wait, relay rank 0's stdout.  This parent never imports torch
-    and never touches the GPU; the children are fresh processes (no exec of a GPU-initialised process)."""
+def launch_group(n, argv, timeout=None, extra_env=None):
+    """Start the N rank processes of ONE group (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* in their environment, as
+    torch.distributed.run would set them), wait (at most `timeout` seconds), return (exit code, rank 0's stdout
+    lines).  This parent never imports torch and never touches the GPU; the children are fresh processes (no exec
+    of a GPU-initialised process).  Only the PIDs started here are ever signalled."""
     import socket
     import threading
 
@@ -91,10 +119,11 @@ def self_launch(n):
     base = dict(os.environ, WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1",
                 MASTER_PORT=str(port), QS_BENCH_SELF_LAUNCHED="1")
     base.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    base.update(extra_env or {})
     procs, rank0_out = [], []
     for r in range(n):
         env = dict(base, RANK=str(r), LOCAL_RANK=str(r))
-        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + list(argv), env=env,
                                       stdout=subprocess.PIPE if r == 0 else sys.stderr, text=True if r == 0 else None))
 
     def drain():
@@ -105,6 +134,7 @@ def self_launch(n):
     reader.start()
     failed = 0
     live = set(range(n))
+    t0 = time.monotonic()
     while live:
         for r in sorted(live):
             rc = procs[r].poll()
@@ -116,12 +146,130 @@ def self_launch(n):
                 print(f"bench.py: rank {r} exited with {rc}; stopping the other ranks", file=sys.stderr)
                 for o in live:
                     procs[o].terminate()          # exactly the PIDs started above
+        if live and timeout is not None and time.monotonic() - t0 > timeout:
+            print(f"bench.py: group not finished after {timeout:.0f} s; stopping its ranks", file=sys.stderr)
+            failed = failed or 124
+            for o in live:
+                procs[o].kill()
+            timeout = None
         time.sleep(0.05)
     reader.join(timeout=10)
+    return failed, rank0_out
+
+
+def self_launch(n, argv=None):
+    """`python bench.py --gpus N` without an external launcher: one group, rank 0's line relayed."""
+    failed, rank0_out = launch_group(n, sys.argv[1:] if argv is None else argv)
     for ln in rank0_out:
         (sys.stdout if ln.lstrip().startswith("{") else sys.stderr).write(ln)
     sys.stdout.flush()
     return failed
+
+
+def _without_option(argv, name, has_value=True):
+    out, skip = [], False
+    for a in argv:
+        if skip:
+            skip = False
+            continue
+        if a == name:
+            skip = has_value
+            continue
+        if a.startswith(name + "="):
+            continue
+        out.append(a)
+    return out
+
+
+def run_legs(args, n, under_launcher):
+    """`--layout auto` at N > 1: every layout of `--legs` measured as its OWN group of fresh rank processes, one after
+    the other; rank 0 composes ONE line.  Without an external launcher this process starts each group itself
+    (`launch_group`).  Under `torch.distributed.run` this process IS rank RANK of the driver's launch: it then starts
+    one child per leg -- its rank of that leg's own process group (own rendezvous port) -- and never touches the GPU
+    itself, so a leg whose communicator code fails or hangs (the RCCL entry points of the C ABI have never run on
+    more than one rank before the driver's node) costs that leg only: the child is killed at `--leg-timeout`, the leg
+    is recorded as failed and the line still carries every other leg."""
+    legs = [x for x in args.legs.split(",") if x]
+    argv = _without_option(sys.argv[1:], "--layout")
+    rank = int(os.environ.get("RANK", "0")) if under_launcher else 0
+    records = {}
+    for k, leg in enumerate(legs):
+        leg_argv = argv + ["--layout", leg]
+        t0 = time.monotonic()
+        if under_launcher:
+            env = {kk: v for kk, v in os.environ.items() if not kk.startswith("TORCHELASTIC")}
+            env["MASTER_PORT"] = str(int(os.environ.get("MASTER_PORT", "29500")) + 1 + k)
+            env["QS_BENCH_LEG"] = leg
+            try:
+                res = subprocess.run([sys.executable, os.path.abspath(__file__)] + leg_argv, env=env,
+                                     stdout=subprocess.PIPE, stderr=sys.stderr, text=True, timeout=args.leg_timeout)
+                rc, lines = res.returncode, res.stdout.splitlines()
+            except subprocess.TimeoutExpired as exc:          # (run() has killed and reaped the child)
+                rc, lines = 124, (exc.stdout or "").splitlines() if isinstance(exc.stdout, str) else []
+        else:
+            rc, lines = launch_group(n, leg_argv, timeout=args.leg_timeout, extra_env={"QS_BENCH_LEG": leg})
+        rec = {"status": "ok" if rc == 0 else f"failed (exit code {rc}{', timed out' if rc == 124 else ''})",
+               "wall_s": time.monotonic() - t0}
+        for ln in lines:
+            if ln.lstrip().startswith("{"):
+                try:
+                    rec["line"] = json.loads(ln)
+                except ValueError:
+                    pass
+        if rc == 0 and "line" not in rec and rank == 0:
+            rec["status"] = "failed (no result line)"
+        records[leg] = rec
+    if rank != 0:
+        return 0
+    return compose_legs(args, n, legs, records)
+
+
+def compose_legs(args, n, legs, records):
+    """ONE line from the legs: `value` = the best leg whose time includes a collective."""
+    summary, candidates = {}, []
+    for leg in legs:
+        rec = records[leg]
+        d = rec.get("line")
+        ent = {"status": rec["status"], "wall_s": round(rec["wall_s"], 1)}
+        if d:
+            ent.update({"value": d["value"], "ms_per_step": d["ms_per_step"], "ms_per_step_median": d.get("ms_per_step_median"),
+                        "layout": d["config"]["layout"], "parity": d["parity"], "collective": d.get("collective", {}).get("in_value"),
+                        "kernel": d["roofline"]["kernel"], "n_ranks_seen": d.get("n_ranks_seen")})
+            ok = rec["status"] == "ok" and d["parity"]["ok"]
+            if "with_all_gather" in d:
+                ent["with_all_gather"] = d["with_all_gather"]
+                if ok:
+                    candidates.append((d["with_all_gather"]["value"], leg + " + all-gather", d, d["with_all_gather"]))
+            if ok and d.get("collective", {}).get("in_value") not in (None, "none"):
+                candidates.append((d["value"], leg, d, None))
+        summary[leg] = ent
+    if not candidates:
+        print("bench.py: no leg with a collective in its time finished", file=sys.stderr)
+        fallback = [records[leg].get("line") for leg in legs if records[leg].get("line")]
+        if not fallback:
+            return 1
+        line = fallback[0]
+        line["legs"] = summary
+        print(json.dumps(line), flush=True)
+        return 0 if line["parity"]["ok"] else 3
+    value, name, d, gathered = max(candidates, key=lambda c: c[0])
+    line = dict(d)
+    line["legs"] = summary
+    line["config"] = dict(d["config"], chosen_leg=name,
+                          choice="best of the legs whose time includes a collective (see `legs`; the no-collective "
+                                 "replicated figure is legs.replicated.value)")
+    if gathered is not None:
+        # the replicated layout followed by the north star's all-gather of the result: its own (shorter) timing leg
+        line["value"] = gathered["value"]
+        line["ms_per_step"] = gathered["ms_per_step"]
+        line["steps"] = gathered["steps"]
+        line["config"]["layout"] = d["config"]["layout"] + ", + all-gather of the result"
+        line["collective"] = {"in_value": "all-gather of the result"}
+        for k in ("ms_per_step_median", "ms_per_step_min", "value_at_median_step", "value_at_min_step", "with_all_gather"):
+            line.pop(k, None)
+        line["config"]["frac_of_mfma_peak"] = gathered["value"] / (MFMA_F64_PEAK_TFLOPS * n)
+    print(json.dumps(line), flush=True)
+    return 0
 
 
 # ----------------------------------------------------------------------------------------------
@@ -202,7 +350,10 @@ def contract4(t, va, vb, vc, vd):
     step = max(1, (1 << 18) // (B * C))
     parts = []
     for a0 in range(0, A, step):
-        x = t[a0:a0 + step].reshape(-1, D) @ vd
+        blk = t[a0:a0 + step]
+        if blk.dtype != vd.dtype:
+            blk = blk.to(vd.dtype)                      # (a real tensor against complex vectors: block-wise, never whole)
+        x = blk.reshape(-1, D) @ vd
         x = x.reshape(-1, C) @ vc
         parts.append(x.reshape(-1, B) @ vb)
     return torch.cat(parts) @ va
@@ -223,10 +374,23 @@ def identity_parts(torch, u_part, out_rows, C, Ct, p_lo, b_lo=None, seed=7):
     yb, zc, wd = Ct.transpose(0, 1) @ y, C @ z, C @ w
     if b_lo is None:      # whole u on this rank: restrict the x-contraction to this rank's rows of Ct
         xa = Ct[p_lo:p_lo + pc].transpose(0, 1) @ x[p_lo:p_lo + pc]
-        rhs = contract4(u_part.to(dt) if u_part.dtype != dt else u_part, xa, yb, zc, wd)
+        rhs = contract4(u_part, xa, yb, zc, wd)
     else:                 # u[:, b_lo:b_hi] on this rank
         xa = Ct.transpose(0, 1) @ x
         rhs = contract4(u_part, xa, yb[b_lo:b_lo + u_part.shape[1]], zc, wd)
+    return lhs, rhs
+
+
+def identity_parts_rows(torch, u_rows, out_rows, C, Ct, a_lo, q_lo, seed=7):
+    """The same property for the rows layouts: this rank holds u[a_lo:a_hi] and out[:, q_lo:q_hi] stored with q leading
+    (out_rows[q, p, r, s]); lhs over its q rows, rhs over its a rows, both summed over the ranks."""
+    l, dt = C.shape[0], out_rows.dtype
+    g = torch.Generator(device=out_rows.device).manual_seed(seed)
+    x, y, z, w = [torch.randn(l, dtype=torch.float64, device=out_rows.device, generator=g).to(dt) for _ in range(4)]
+    C, Ct = C.to(dt), Ct.to(dt)
+    lhs = contract4(out_rows, y[q_lo:q_lo + out_rows.shape[0]], x, z, w)
+    xa, yb, zc, wd = Ct.transpose(0, 1) @ x, Ct.transpose(0, 1) @ y, C @ z, C @ w
+    rhs = contract4(u_rows, xa[a_lo:a_lo + u_rows.shape[0]], yb, zc, wd)
     return lhs, rhs
 
 
@@ -521,11 +685,16 @@ def run_rank(args):
     if args.workload != "transform":
         return bandwidth_workload(args, torch, dist, kernels, sharded, device, rank, world, use_dist, ranks_seen)
     l = args.l
-    dtype = torch.float64 if args.dtype == "f64" else torch.complex128
+    mixed = args.dtype == "mixed"
+    dtype = torch.float64 if args.dtype == "f64" else torch.complex128          # of C and of the result
+    u_dtype = torch.float64 if mixed else dtype
     es = 8 if args.dtype == "f64" else 16
     kf = 1 if args.dtype == "f64" else 4
-    flops = kf * 8 * l**5
-    fresh_c = args.fresh_c == "on" or (args.fresh_c == "auto" and args.dtype == "c128")
+    # algorithmic flops: 8 l^5 real, 32 l^5 complex; real u x complex C: the d contraction is a real-by-complex product
+    # (4 flops per multiply-add instead of 8): 4 l^5 + 3 * 8 l^5
+    flops = 28 * l**5 if mixed else kf * 8 * l**5
+    kernels.mixed_real_u = args.mixed_route == "native"
+    fresh_c = args.fresh_c == "on" or (args.fresh_c == "auto" and args.dtype in ("c128", "mixed"))
     part = sharded.SlabPartition(l, world)
     p_lo, p_hi = part.bounds(rank)
 
@@ -537,6 +706,10 @@ def run_rank(args):
         layout_kind = "replicated" if l**4 * es * (1 + 4 / world) < 0.85 * HBM_BYTES else "inplace"
     if layout_kind == "inplace" and l % world:
         raise SystemExit("--layout inplace needs l divisible by the number of GPUs")
+    if layout_kind in ("rccl", "rows_rccl") and world > 1 and (single_dev or backend != "nccl"):
+        raise SystemExit(f"--layout {layout_kind} drives RCCL directly: one GPU per rank (not available in the one-device rehearsal)")
+    if mixed and layout_kind not in ("single", "rows", "rows_rccl"):
+        raise SystemExit("--dtype mixed: single GPU or the rows layouts")
 
     def barrier():
         if use_dist:
@@ -546,12 +719,16 @@ def run_rank(args):
     # ---- inputs.  Coefficients: one unitary (fp64 default: a single change_basis) or a new one per step
     n_c = (args.steps + args.warmup) if fresh_c else 1
     Cs = [make_unitary(torch, l, dtype, device, 99 + i) for i in range(n_c)]
-    b_lo = None
+    b_lo = a_lo = None
     if layout_kind in ("single", "replicated"):
-        u, C0, _ = make_inputs(torch, l, dtype, device)
+        u, C0, _ = make_inputs(torch, l, u_dtype, device)
         if not fresh_c:
             Cs = [C0]
         data = "synthetic"
+    elif layout_kind in ("rows", "rows_rccl"):
+        a_lo, a_hi = part.bounds(rank)
+        u = make_u_slab(torch, l, u_dtype, device, 0, a_lo, a_hi)
+        data = "synthetic (rows of the leading index generated per rank, not symmetrised)"
     else:
         b_lo, b_hi = part.bounds(rank)
         u = make_u_slab(torch, l, dtype, device, 1, b_lo, b_hi)
@@ -573,8 +750,16 @@ def run_rank(args):
             full_buf[0] = torch.empty((l, l, l, l), dtype=dtype, device=device)
         return sharded.all_gather_slabs(o, l, rank, world, full=full_buf[0])
 
+    rccl_comm = None
+    if layout_kind in ("rccl", "rows_rccl"):
+        ids = [kernels.RcclComm.unique_id() if rank == 0 else None]
+        if use_dist:
+            dist.broadcast_object_list(ids, src=0)         # 128 bytes, by the job's existing rendezvous
+        with _StdoutToStderr():
+            rccl_comm = kernels.RcclComm(rank, world, ids[0])
+
     if layout_kind == "single":
-        out = torch.empty_like(u)
+        out = torch.empty(u.shape, dtype=dtype, device=device)
 
         def local_step(i):
             C, Ct = coeff(i)
@@ -590,12 +775,22 @@ def run_rank(args):
             C, Ct = coeff(i)
             return sharded.transform_two_body_sharded(u, C, Ct, rank, world)
         layout = "u b-sharded, one all-to-all, out p-sharded (out of place)"
+    elif layout_kind in ("rows", "rows_rccl"):
+        keep = torch.empty(sharded.rows_buffer_elems(l, l, p_hi - p_lo), dtype=dtype, device=device)
+        if layout_kind == "rows":
+            def local_step(i):
+                C, Ct = coeff(i)
+                return sharded.transform_two_body_rows(u, C, Ct, rank, world, chunk_rows=args.chunk_rows or None, out=keep)
+            layout = ("u sharded over its leading index and resident, out over its second (rows in, rows out): streamed, "
+                      "input rows + result rows + O(l^3) per GPU, one all-to-all per chunk of rows (torch.distributed)")
+        else:
+            def local_step(i):
+                C, Ct = coeff(i)
+                return rccl_comm.transform_two_body_rows(u, C, Ct, chunk_rows=args.chunk_rows, out=keep)
+            layout = ("u sharded over its leading index and resident, out over its second (rows in, rows out): ONE C-ABI "
+                      "call, input rows + result rows + O(l^3) per GPU, RCCL grouped send/recv per chunk of rows on its "
+                      "own stream under the next chunk's products")
     elif layout_kind == "rccl":
-        ids = [kernels.RcclComm.unique_id() if rank == 0 else None]
-        if use_dist:
-            dist.broadcast_object_list(ids, src=0)         # 128 bytes, by the job's existing rendezvous
-        with _StdoutToStderr():
-            rccl_comm = kernels.RcclComm(rank, world, ids[0])
         out_slab = torch.empty((p_hi - p_lo, l, l, l), dtype=dtype, device=device)
 
         def local_step(i):
@@ -650,7 +845,10 @@ def run_rank(args):
     C_last = Cs[last_i % n_c]
     Ct_last = Cts[last_i % n_c]
     rows = res[p_lo:p_hi] if layout_kind == "single" else res
-    lhs, rhs = identity_parts(torch, u, rows, C_last, Ct_last, p_lo, b_lo=b_lo)
+    if layout_kind in ("rows", "rows_rccl"):
+        lhs, rhs = identity_parts_rows(torch, u, rows, C_last, Ct_last, a_lo, p_lo)
+    else:
+        lhs, rhs = identity_parts(torch, u, rows, C_last, Ct_last, p_lo, b_lo=b_lo)
     pair = torch.stack([lhs, rhs]).to(torch.complex128)
     if use_dist:
         pr = torch.view_as_real(pair).contiguous()
@@ -718,17 +916,20 @@ def run_rank(args):
 
     med, mn = median(per_step), min(per_step)
     line = {
-        "metric": f"4-index u transform TFLOP/s ({'fp64' if kf == 1 else 'complex128'}) at L={l} orbitals",
+        "metric": f"4-index u transform TFLOP/s ({'fp64' if kf == 1 else ('real u x complex C' if mixed else 'complex128')}) "
+                  f"at L={l} orbitals",
         "value": value, "unit": "TFLOP/s", "n_gpus": world, "n_ranks_seen": ranks_seen,
         "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": ms_per_step, "ms_per_step_median": med, "ms_per_step_min": mn,
         "value_at_median_step": flops / (med * 1e-3) / 1e12, "value_at_min_step": flops / (mn * 1e-3) / 1e12,
         "higher_is_better": True, "scaling": "strong",
-        "vs_baseline": None, "dtype": args.dtype, "data": data,
+        "vs_baseline": None, "dtype": "f64 u, c128 C and result" if mixed else args.dtype, "data": data,
         "config": {
-            "workload": f"RandomBasisSet-shaped l={l} {args.dtype} four-index transform "
-                        f"(BASELINE.json configs[{(1 if l == 55 else 2) if kf == 1 else 4}]), u resident in HBM, C unitary"
-                        + (", a new C every step (C_tilde derived inside the call)" if fresh_c else ""),
+            "workload": f"RandomBasisSet-shaped l={l} {'real-fp64-u x complex128-C' if mixed else args.dtype} four-index transform "
+                        f"(BASELINE.json configs[{(1 if l == 55 else 2) if kf == 1 else 4}]"
+                        + (" call pattern on a real u" if mixed else "") + "), u resident in HBM, C unitary"
+                        + (", a new C every step (C_tilde derived inside the call)" if fresh_c else "")
+                        + (f"; route: {'the real tensor read as it is (d contraction real x complex)' if args.mixed_route == 'native' else 'complex copy of u first (rounds 1-2)'}; flops counted 4 l^5 + 24 l^5" if mixed else ""),
             "l": l, "flops_per_step": flops, "layout": layout,
             "frac_of_mfma_peak": value / (MFMA_F64_PEAK_TFLOPS * world),
         },
@@ -738,7 +939,9 @@ def run_rank(args):
     }
     if world > 1:
         line["collective"] = {"in_value": "all-gather of the result" if with_gather else (
-            "none" if layout_kind == "replicated" else "one all-to-all (re-shard of the intermediate)")}
+            "none" if layout_kind == "replicated" else (
+                "one all-to-all per chunk of input rows (re-shard of the intermediate)" if layout_kind in ("rows", "rows_rccl")
+                else "one all-to-all (re-shard of the intermediate)"))}
         if gather_leg:
             e2, k2, _ = gather_leg
             line["with_all_gather"] = {"value": flops * k2 / e2 / 1e12, "ms_per_step": e2 / k2 * 1e3, "steps": k2,
@@ -754,9 +957,30 @@ def run_rank(args):
     return 0 if parity_ok else 3
 
 
+def apply_config(args):
+    """`--config N`: the workload BASELINE.json configs[N] names, without flag knowledge."""
+    if args.config == 3:
+        args.workload, args.l = "spin_expand", 256
+    elif args.config == 4:
+        n = int(os.environ.get("WORLD_SIZE", args.gpus))
+        # input rows + result rows (+ one row, scratch) per rank within ~85 % of the HBM; 512 at 8 GPUs
+        l = 512
+        while l > 64 and 2 * l**4 * 16 / n + 8 * l**3 * 16 > 0.85 * HBM_BYTES:
+            l -= 64
+        args.l, args.dtype, args.fresh_c = l, "c128", "on"
+        if args.layout == "auto":
+            args.layout = "rows_rccl" if (n > 1 and os.environ.get("QS_BENCH_BACKEND", "nccl") == "nccl") else "rows"
+    return args
+
+
 def main():
-    args = parse()
-    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+    args = apply_config(parse())
+    under_launcher = "WORLD_SIZE" in os.environ
+    n = int(os.environ["WORLD_SIZE"]) if under_launcher else args.gpus
+    if (n > 1 and args.layout == "auto" and args.workload == "transform" and "QS_BENCH_LEG" not in os.environ
+            and os.environ.get("QS_BENCH_SELF_LAUNCHED") != "1"):
+        return run_legs(args, n, under_launcher)
+    if args.gpus > 1 and not under_launcher:
         return self_launch(args.gpus)
     return run_rank(args)
 

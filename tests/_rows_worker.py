@@ -37,7 +37,11 @@ def main():
         dC, dCt = torch.from_numpy(C).to(dev), torch.from_numpy(Ct).to(dev)
         i_lo, i_hi = sharded.SlabPartition(L, world).bounds(rank)
         j_lo, j_hi = sharded.SlabPartition(M, world).bounds(rank)
-        # the out-of-place layouts of rounds 1-2 on the same numbers (what "bit-equal to today's layouts" refers to)
+        # the single-GPU transform of the same numbers: every element one chain of fused multiply-adds per contraction, in
+        # index order -- the streamed layout keeps exactly those chains (each product has the WHOLE contracted index)
+        whole = K.transform_two_body(torch.from_numpy(u).to(dev), dC, dCt)
+        # the out-of-place layouts of rounds 1-2 on the same numbers: they close the sharded index peer block by peer
+        # block (accumulating products), so beyond one rank they agree to rounding only
         old_a = sharded.transform_two_body_sharded_a(torch.from_numpy(np.ascontiguousarray(u[i_lo:i_hi])).to(dev), dC, dCt,
                                                      rank, world)                    # (M, ql, M, M) = out[:, q_lo:q_hi]
         old_b = sharded.transform_two_body_sharded(torch.from_numpy(np.ascontiguousarray(u[:, i_lo:i_hi])).to(dev), dC, dCt,
@@ -62,10 +66,18 @@ def main():
                 assert peak <= bound, (L, M, ni, peak, bound)
                 g = got.cpu().numpy()
                 assert np.abs(g - want[j_lo:j_hi]).max() <= 1e-10 * np.abs(ref).max(), (L, M, second, ni)
+                mine = whole[j_lo:j_hi] if second else whole[:, j_lo:j_hi].transpose(0, 1)
+                if not second:
+                    assert torch.equal(got, mine), (L, M, second, ni)                # d, c, b, a: the same sums in the same order
+                else:                                                                # d, c, a, b (the order of the b-sharded layouts)
+                    assert (got - mine).abs().max().item() <= 1e-12 * mine.abs().max().item(), (L, M, second, ni)
                 old = old_b if second else old_a.transpose(0, 1)
-                assert torch.equal(got, old), (L, M, second, ni)                     # the same sums in the same order
+                if world == 1:
+                    assert torch.equal(got, old), (L, M, second, ni)
+                else:
+                    assert (got - old).abs().max().item() <= 1e-12 * old.abs().max().item(), (L, M, second, ni)
                 del got
-        del old_a, old_b
+        del old_a, old_b, whole
     # ---- through the array module: ShardedTensor4 in, ShardedTensor4 out, the sharded index flips and flips back
     mod = qsa.ShardedDeviceModule(rank, world, device="cuda:0")
     assert mod.rccl() is None                          # gloo: the exchange goes through torch.distributed

@@ -106,11 +106,78 @@ def test_two_rank_self_launch(layout):
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["n_ranks_seen"] == 2 and d["steps"] == 3 and d["value"] > 0
     assert d["parity"]["ok"] is True and d["parity"]["randomised_identity_rel_diff"] <= 1e-10
-    if layout in ("auto", "replicated"):
+    if layout == "replicated":
         assert d["collective"]["in_value"] == "none" and d["with_all_gather"]["value"] > 0
         assert d["with_all_gather"]["value"] <= d["value"] * 1.05
+    if layout == "auto":
+        # the driver's one command: every layout measured as its own group of rank processes, ONE line; `value` is the
+        # best leg whose time includes a collective, and it is named
+        legs = d["legs"]
+        assert list(legs) == ["replicated", "rows", "rows_rccl", "rccl"]
+        assert legs["replicated"]["status"] == "ok" and legs["rows"]["status"] == "ok"
+        assert legs["replicated"]["collective"] == "none" and legs["replicated"]["with_all_gather"]["value"] > 0
+        assert "all-to-all per chunk" in legs["rows"]["collective"] and legs["rows"]["parity"]["ok"] is True
+        # RCCL driven directly needs one GPU per rank: in the one-device rehearsal those legs are recorded as failed
+        # and cost nothing else
+        assert legs["rows_rccl"]["status"].startswith("failed") and legs["rccl"]["status"].startswith("failed")
+        assert d["config"]["chosen_leg"] in ("rows", "replicated + all-gather")
+        assert d["collective"]["in_value"] != "none"
+        best = max(legs["rows"]["value"], legs["replicated"]["with_all_gather"]["value"])
+        assert abs(d["value"] - best) <= 1e-9 * best
     if layout == "inplace":
         assert "in place" in d["config"]["layout"] and "per rank" in d["data"]
+
+
+def test_default_layout_under_the_external_launcher_runs_every_leg():
+    # `python -m torch.distributed.run ... bench.py --gpus 2` exactly as the driver issues it (no --layout): every rank
+    # process starts one child per leg and never touches the GPU itself; rank 0 prints the ONE composed line
+    env = dict(os.environ, **REHEARSAL)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+           "--master-addr", "127.0.0.1", "--master-port", "29681",
+           os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--orbitals", "48",
+           "--no-cpu-baseline", "--no-probes", "--legs", "replicated,rows,rows_rccl"]
+    res = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
+    assert res.returncode == 0, res.stderr[-3000:]
+    lines = [ln for ln in res.stdout.splitlines() if ln.strip().startswith("{")]
+    assert len(lines) == 1, res.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["n_ranks_seen"] == 2 and d["parity"]["ok"] is True
+    assert d["legs"]["replicated"]["status"] == "ok" and d["legs"]["rows"]["status"] == "ok"
+    assert d["legs"]["rows_rccl"]["status"].startswith("failed")
+    assert d["config"]["chosen_leg"] in ("rows", "replicated + all-gather") and d["value"] > 0
+
+
+def test_rows_layouts_with_a_one_rank_group():
+    # the rows layouts (what ShardedDeviceModule runs) as bench legs: torch.distributed-driven and as ONE C-ABI call on
+    # a real RCCL communicator (one rank here)
+    for layout, port in (("rows", "29692"), ("rows_rccl", "29693")):
+        env = dict(os.environ, QS_BENCH_FORCE_DIST="1", MASTER_ADDR="127.0.0.1", MASTER_PORT=port,
+                   RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
+        cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "3", "--warmup", "1",
+               "--orbitals", "64", "--layout", layout, "--no-cpu-baseline", "--no-probes", "--chunk-rows", "16"]
+        res = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=ROOT, env=env)
+        assert res.returncode == 0, res.stderr[-3000:]
+        d = json.loads([ln for ln in res.stdout.splitlines() if ln.strip().startswith("{")][0])
+        assert "rows in, rows out" in d["config"]["layout"] and d["parity"]["ok"] is True and d["n_ranks_seen"] == 1
+        if layout == "rows_rccl":
+            assert "rccl grouped send/recv (4 steps of 16 rows)" in d["roofline"]["dispatch"]
+
+
+def test_config_presets_and_the_mixed_dtype():
+    # --config 3 / 4: BASELINE.json configs[3] and [4] without flag knowledge
+    d = run_bench("--config", "3", "--steps", "1", "--warmup", "0")
+    assert "configs[3]" in d["config"]["workload"] and d["config"]["l"] == 256 and d["unit"] == "GB/s"
+    d = run_bench("--config", "4", "--steps", "1", "--warmup", "0", "--no-cpu-baseline", "--no-probes")
+    # one GPU holds input rows + result rows of l = 256 complex128 (l = 512 needs the 8-GPU node)
+    assert d["config"]["l"] == 256 and d["dtype"] == "c128" and "a new C every step" in d["config"]["workload"]
+    assert "rows in, rows out" in d["config"]["layout"] and d["parity"]["ok"] is True
+    # --dtype mixed: a real u against complex coefficients, natively and through the complex copy of rounds 1-2
+    a = run_bench("--orbitals", "64", "--dtype", "mixed", "--no-cpu-baseline", "--no-probes")
+    b = run_bench("--orbitals", "64", "--dtype", "mixed", "--mixed-route", "cast", "--no-cpu-baseline", "--no-probes")
+    for d in (a, b):
+        assert d["parity"]["ok"] is True and d["config"]["flops_per_step"] == 28 * 64**5
+    assert "read as it is" in a["config"]["workload"] and "complex copy" in b["config"]["workload"]
+    assert "<false" in a["roofline"]["dispatch"] and "<false" not in b["roofline"]["dispatch"]
 
 
 def test_self_launch_bandwidth_workload_two_ranks():
