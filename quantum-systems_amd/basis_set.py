@@ -406,9 +406,32 @@ class BasisSet:
             c, ct = coeffs(arr)
             return _deliver(kernels.transform_one_body(arr, c, ct), np)
 
-        self.h = one_body(self.h)
-        if self.s is not None:
-            self.s = one_body(self.s)
+        # h, s, position[dim], momentum[dim] (:358-366, :384-406) as ONE stacked call -- two launches for all of them
+        # instead of two per array, one trip through the wrapper (the host side of a small basis costs more than its
+        # kernels) -- when they share a dtype; the results are handed out as the slices of one (n, M, M) array
+        names = [k for k in ("h", "s", "position", "momentum") if getattr(self, k) is not None]
+        mats = [_stage(getattr(self, k)) for k in names]
+        stacked = len(mats) > 1 and all(isinstance(m, torch.Tensor) and m.dtype == mats[0].dtype
+                                        and tuple(m.shape[-2:]) == tuple(mats[0].shape[-2:]) for m in mats)
+        if stacked:
+            L_old = mats[0].shape[-1]
+            counts = [m.numel() // (L_old * L_old) for m in mats]
+            pile = torch.cat([m.reshape(-1, L_old, L_old) for m in mats])
+            c, ct = coeffs(pile)
+            res = kernels.transform_one_body(pile, c, ct)
+            done, at = {}, 0
+            for k, m, cnt in zip(names, mats, counts):
+                part = res[at] if m.dim() == 2 else res[at:at + cnt]
+                done[k] = _deliver(part, np)
+                at += cnt
+            self.h = done["h"]
+            if "s" in done:
+                self.s = done["s"]
+        else:
+            done = {}
+            self.h = one_body(self.h)
+            if self.s is not None:
+                self.s = one_body(self.s)
         # :368-372 transforms spin_x/y/z/spin_2 into a loop local and drops
         # the result; they keep their old values (and shapes) here as well.
 
@@ -462,9 +485,9 @@ class BasisSet:
             del res
 
         if self.position is not None:
-            self.position = one_body(self.position)             # stacked (dim, l, l)
+            self.position = done["position"] if "position" in done else one_body(self.position)    # (dim, l, l)
         if self.momentum is not None:
-            self.momentum = one_body(self.momentum)
+            self.momentum = done["momentum"] if "momentum" in done else one_body(self.momentum)
         if self.spf is not None:
             bra = self.transform_bra_spf(self.bra_spf, coeffs(_stage(self.bra_spf))[1], np)
             ket = self.transform_spf(self.spf, coeffs(_stage(self.spf))[0], np)

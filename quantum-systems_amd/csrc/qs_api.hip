@@ -217,6 +217,7 @@ int qs_tuning_set(const char* key, int64_t value) {
     if (!strcmp(key, "gemm_fast_persist")) { g_tune.gemm_fast_persist = (int)value; return QS_OK; }
     if (!strcmp(key, "gemm_fast_shape")) { g_tune.gemm_fast_shape = (int)value; return QS_OK; }
     if (!strcmp(key, "gemm_pick")) { g_tune.gemm_pick = (int)value; return QS_OK; }
+    if (!strcmp(key, "small4")) { g_tune.small4 = (int)value; return QS_OK; }
     if (!strcmp(key, "sandwich")) { g_tune.sandwich = (int)value; return QS_OK; }
     if (!strcmp(key, "sandwich_mode")) { g_tune.sandwich_mode = (int)value; return QS_OK; }
     if (!strcmp(key, "sandwich_t2")) { g_tune.sandwich_t2 = (int)value; return QS_OK; }
@@ -280,6 +281,22 @@ static int transform_two_body_impl(int in_dtype, int dtype, const void* u, const
     void* WA = at(work, even_up(L * M), es);
     const int64_t wa = (L * L * L * M > L * M * M * M) ? L * L * L * M : L * M * M * M;
     void* WB = (M < L) ? at(WA, wa, es) : out;
+
+    // up to 32 orbitals, both dtypes: two launches of the LDS-staged kernel (what is left below ~33 orbitals is launches, not
+    // work: the 16-wide kernels need three to five); T2 (L, L, M, M) in WA
+    // (same-box sweep with the launches of a transform captured in one graph, profiles/r03_small4.txt: 1.8-2.9x up to 15
+    // orbitals for both dtypes, 1.1-1.4x for complex128 up to 24; fp64 from 17 and complex128 from 25 orbitals level
+    // with the 16-wide kernels or behind them -- what the kernel waits for there is the one round trip of its loads and the
+    // drain of its stores, with one workgroup per CU and nothing to overlap them with.  g_tune.small4 == 2: wherever it exists)
+    const int64_t n4s = cdiv(L, 4);
+    if (in_dtype == dtype && g_tune.small4 && L <= 32 && M <= 32 && n4s == cdiv(M, 4) &&
+        (g_tune.small4 == 2 || n4s <= (dtype == QS_C128 ? 6 : 4))) {
+        const int64_t MM = M * M;
+        int rc1 = small4_try(dtype, u, WA, C, M, 1, C, 1, M, L * L, L, M, L * L, L, 1, MM, M, 1, 0, s);
+        if (rc1 == QS_OK)
+            rc1 = small4_try(dtype, WA, out, Ct, 1, L, Ct, L, 1, MM, L, M, 1, L * MM, MM, 1, M * MM, MM, 1, s);
+        if (rc1 != 1) return rc1;
+    }
 
     // small bases: two passes over the tensor instead of four -- (d, c) per slab u[a, b], then (b, a) per
     // column (r, s): out[:, :, rs] = Ct . T2[:, :, rs] . Ct^T (the same k-ordered sums, element for element)

@@ -115,6 +115,61 @@ def test_mixed_real_u_complex_C_runs_without_a_complex_copy_of_u(K, golden):
     assert lib.qs_transform_two_body_mixed(u4.data_ptr(), C4.data_ptr(), C4.data_ptr(), o4.data_ptr(), w.data_ptr(), w.numel(), 4, 4, s0) == 0
 
 
+@pytest.mark.parametrize("cplx", [False, True])
+def test_small_basis_kernel_is_bit_identical_to_the_16_wide_path(K, cplx):
+    # qs_small4.hip: both fused passes of a basis of <= 32 orbitals, fp64 AND complex128, two launches.  Every element is
+    # the same chain of fused multiply-adds as on the 16-wide kernels (for complex128 including the order of the two
+    # imaginary-part products of each contraction), so the results are bit-identical; against the oracle <= 1e-10.
+    rng = np.random.default_rng(40 + cplx)
+    shapes = [(l, l) for l in (1, 2, 3, 4, 5, 7, 8, 9, 12, 13, 16, 17, 20, 21, 24, 27, 28, 29, 31, 32)]
+    shapes += [(5, 7), (8, 6), (18, 20), (20, 17), (30, 32), (32, 29)]           # rectangular within one quad count
+    for (L, M) in shapes:
+        u = rng.standard_normal((L,) * 4)
+        C = rng.standard_normal((L, M)) / np.sqrt(L)
+        Ct = rng.standard_normal((M, L)) / np.sqrt(L)
+        if cplx:
+            u = u + 1j * rng.standard_normal((L,) * 4)
+            C = C + 1j * rng.standard_normal((L, M)) / np.sqrt(L)
+            Ct = Ct + 1j * rng.standard_normal((M, L)) / np.sqrt(L)
+        du, dC, dCt = dev(u), dev(C), dev(Ct)
+        auto = max(L, M) <= (24 if cplx else 16)          # where it measured faster (profiles/r03_small4.txt)
+        if not auto:
+            K.tuning_set("small4", 2)                      # ... and wherever it exists
+        try:
+            got = K.transform_two_body(du, dC, dCt)
+            ran = K.last_dispatch()
+        finally:
+            K.tuning_reset()
+        assert ran == f"qs::small4_kernel<{'true' if cplx else 'false'}, {-(-L // 4)}> x2", (L, M, ran)
+        if not auto:
+            K.transform_two_body(du, dC, dCt)
+            assert "small4" not in K.last_dispatch(), (L, M)
+        K.tuning_set("small4", 0)
+        try:
+            wide = K.transform_two_body(du, dC, dCt)
+            assert "small4" not in K.last_dispatch()
+        finally:
+            K.tuning_reset()
+        assert torch.equal(got, wide), (L, M)
+        if L <= 20:
+            assert relerr(host(got), orc.transform_two_body(u, C, Ct)) <= RTOL, (L, M)
+    # a different quad count for L and M, more than 32 orbitals, a real tensor against complex coefficients: other kernels
+    for (L, M) in ((8, 9), (33, 33), (16, 12)):
+        K.transform_two_body(dev(rng.standard_normal((L,) * 4)), dev(rng.standard_normal((L, M))))
+        assert "small4" not in K.last_dispatch()
+    K.transform_two_body(dev(rng.standard_normal((8,) * 4)), dev(crand(rng, 8, 8)))
+    assert "small4" not in K.last_dispatch()
+    # odd item counts (the last item quad is incomplete) next to live memory: a slab of a larger tensor, rows after it poisoned
+    L = 5
+    big = torch.full((L + 1, L, L, L), float("nan"), dtype=torch.float64, device="cuda")
+    uu = rng.standard_normal((L,) * 4)
+    big[:L] = dev(uu)
+    Cn = rng.standard_normal((L, L))
+    got = K.transform_two_body(big[:L], dev(Cn))
+    assert "small4" in K.last_dispatch() and torch.isfinite(got).all()
+    assert relerr(host(got), orc.transform_two_body(uu, Cn)) <= RTOL
+
+
 def test_spf_golden(K, golden):
     g = golden("transform_spf")
     L = g["C"].shape[0]

@@ -18,17 +18,17 @@ for d in sorted(glob.glob(os.path.join(root, "*/"))):
         longest = defaultdict(float)
         for r in rows:
             if r.get("End_Timestamp"):
-                d = float(r["End_Timestamp"]) - float(r["Start_Timestamp"])
-                longest[r["Kernel_Name"][:60]] = max(longest[r["Kernel_Name"][:60]], d)
+                dur = float(r["End_Timestamp"]) - float(r["Start_Timestamp"])
+                longest[r["Kernel_Name"][:60]] = max(longest[r["Kernel_Name"][:60]], dur)
         for r in rows:
             name = r["Kernel_Name"][:60]
             acc[name][r["Counter_Name"]].append(float(r["Counter_Value"]))
             if "Start_Timestamp" in r and r.get("End_Timestamp"):
-                d = float(r["End_Timestamp"]) - float(r["Start_Timestamp"])
-                acc[name]["_dur_ns"].append(d)
-                if d >= 0.5 * longest[name]:
+                dur = float(r["End_Timestamp"]) - float(r["Start_Timestamp"])
+                acc[name]["_dur_ns"].append(dur)
+                if dur >= 0.5 * longest[name]:
                     full[name][r["Counter_Name"]].append(float(r["Counter_Value"]))
-                    full[name]["_dur_ns"].append(d)
+                    full[name]["_dur_ns"].append(dur)
         print(f"== {os.path.basename(os.path.dirname(d))}")
         for name, cs in acc.items():
             if not (name.startswith("void qs::") or name.startswith("qs::")):
