@@ -618,6 +618,16 @@ def bandwidth_workload(args, torch, dist, kernels, sharded, device, rank, world,
         gbps = step_bytes * args.steps / elapsed / 1e9
         per_launch = dev_elapsed / (args.steps * launches)
         achieved = step_bytes / world / launches / per_launch / 1e9
+        traffic = traffic_source = None
+        prof = os.path.join(ROOT, "profiles", "traffic_latest.json")
+        if world == 1 and os.path.exists(prof):          # HBM bytes per (full-size) launch from this round's PMC passes
+            try:
+                with open(prof) as f:
+                    for ent in json.load(f):
+                        if ent.get("workload") == args.workload and ent.get("l") == l and ent.get("kernel") == kernel:
+                            traffic, traffic_source = ent["hbm_bytes_per_launch"], ent.get("source")
+            except Exception:
+                pass
         line = {
             "metric": f"{name} GB/s (algorithmic bytes) at l={l} spatial orbitals",
             "value": gbps, "unit": "GB/s", "n_gpus": world, "n_ranks_seen": ranks_seen,
@@ -631,7 +641,8 @@ def bandwidth_workload(args, torch, dist, kernels, sharded, device, rank, world,
                                    else f"anti-symmetrisation of real fp64 u l={l}, p-slab per GPU",
                        "l": l, "bytes_per_step": step_bytes},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBPS, "traffic": None, "kernel": kernel, "dispatch": dispatch,
+                         "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic, "traffic_source": traffic_source,
+                         "kernel": kernel, "dispatch": dispatch,
                          "bytes_per_launch": step_bytes / world / launches, "avg_launch_ms": per_launch * 1e3},
             "parity": {"value_exact_vs_definition": exact},
         }
