@@ -78,8 +78,57 @@ int main() {
     EXPECT(qs_comm_destroy(nullptr) == QS_ERR_NULL_POINTER);
     EXPECT(qs_comm_rank(nullptr) < 0 && qs_comm_world(nullptr) < 0);
     EXPECT(qs_transform_two_body_sharded(nullptr, QS_F64, p, p, p, buf + 32, buf + 16, 1 << 20, 4, 4, 4, nullptr) == QS_ERR_NULL_POINTER);
+    EXPECT(qs_comm_abort(nullptr) == QS_ERR_NULL_POINTER);
+    // the mixed transform (real u, complex coefficients) and the rows-in / rows-out sharded transform (round 3)
+    EXPECT(qs_transform_two_body_mixed(p, p, p, p, buf + 16, 1 << 20, 4, 4, nullptr) == QS_ERR_ALIAS);
+    EXPECT(qs_transform_two_body_mixed(nullptr, p, p, buf + 32, buf + 16, 1 << 20, 2, 2, nullptr) == QS_ERR_NULL_POINTER);
+    EXPECT(qs_transform_two_body_mixed(p, (char*)buf + 8, p, buf + 32, buf + 16, 1 << 20, 2, 2, nullptr) == QS_ERR_MISALIGNED);
+    EXPECT(qs_transform_two_body_mixed(p, p, p, buf + 32, buf + 16, 8, 2, 2, nullptr) == QS_ERR_WORKSPACE);
+    EXPECT(qs_transform_two_body_sharded_rows(nullptr, QS_F64, QS_F64, p, nullptr, p, p, buf + 32, 1 << 20, buf + 16, 1 << 20, 4, 4, 1,
+                                              nullptr) == QS_ERR_NULL_POINTER);
+    EXPECT(qs_transform_two_body_sharded_rows_workspace(QS_F64, 8, 8, 0) < 0);
+    EXPECT(qs_transform_two_body_sharded_rows_workspace(QS_F64, 8, 8, 9) < 0);
+    EXPECT(qs_transform_two_body_sharded_rows_workspace(QS_F64, 8, 8, 2) == 8 * (64 + 2 * 8 * 8 * 8 + 2 * 8 * 64 + 2 * 8 * 2 * 64 + 8));
+    EXPECT(qs_transform_two_body_sharded_rows_out_bytes(QS_C128, 8, 6, 2, 0) == 16 * (3 * 8 * 36 + 8 * 36));
+    EXPECT(qs_transform_two_body_sharded_rows_out_bytes(QS_C128, 6, 8, 2, 1) == 16 * (4 * 8 * 64 + 6 * 64));
+    EXPECT(qs_transform_two_body_sharded_rows_out_bytes(9, 8, 8, 2, 0) == QS_ERR_BAD_DTYPE);
+    EXPECT(qs_sharded_rows_default_chunk(QS_F64, 256, 256, 8, nullptr) == 8);
+    EXPECT(qs_sharded_rows_default_chunk(QS_C128, 512, 512, 8, nullptr) == 1);
+    {
+        const int64_t bad_starts[3] = {0, 5, 7};             // does not end at L
+        EXPECT(qs_sharded_rows_default_chunk(QS_F64, 8, 8, 2, bad_starts) == QS_ERR_BAD_EXTENT);
+        const int64_t back[3] = {0, 9, 8};                   // goes backwards
+        EXPECT(qs_sharded_rows_default_chunk(QS_F64, 8, 8, 2, back) == QS_ERR_BAD_EXTENT);
+    }
+    // its exchange plan (pure host arithmetic): balanced, uneven and spin-doubled partitions, several chunk sizes
+    for (int world : {1, 2, 3, 8}) {
+        for (int rank = 0; rank < world; ++rank) {
+            const int64_t L = 18, M = 13;
+            std::vector<int64_t> header(8), table(7 * 4096), starts(world + 1);
+            for (int g = 0; g <= world; ++g) {               // twice the balanced offsets of 9 spatial rows
+                const int64_t base = 9 / world, extra = 9 % world;
+                starts[g] = 2 * (g * base + (g < extra ? g : extra));
+            }
+            for (int64_t chunk : {0, 1, 2, 5, 64}) {
+                for (const int64_t* st : {(const int64_t*)nullptr, (const int64_t*)starts.data()}) {
+                    const int n = qs_sharded_rows_exchange_plan(L, M, world, rank, st, chunk, header.data(), table.data(), 4096);
+                    EXPECT(n >= 0);
+                    const int64_t jl = header[2], r0 = header[4], out_elems = header[5], ni = header[6], nsteps = header[7];
+                    EXPECT(ni >= 1 && nsteps * ni >= header[3] && (nsteps - 1) * ni < header[3]);
+                    EXPECT(out_elems == jl * 18 * M * M + L * M * M && r0 + jl * L * M * M == out_elems);
+                    for (int i = 0; i < n; ++i) {            // every operation stays inside the send block / the result buffer
+                        const int64_t* op = &table[7 * i];
+                        EXPECT(op[0] >= 0 && op[0] < nsteps && op[1] >= 0 && op[1] < world && op[5] > 0);
+                        if (op[2] != 0) EXPECT(op[4] >= r0 && op[4] + (op[6] - 1) * L * M * M + op[5] <= out_elems);
+                        if (op[2] != 1) EXPECT(op[3] >= 0 && op[3] + op[5] * op[6] <= M * ni * M * M);
+                    }
+                    if (n > 0) EXPECT(qs_sharded_rows_exchange_plan(L, M, world, rank, st, chunk, header.data(), table.data(), 0) == QS_ERR_WORKSPACE);
+                }
+            }
+        }
+    }
     // tuning state: thread-local, reset
-    EXPECT(qs_tuning_set("gemm_fast", 0) == QS_OK && qs_tuning_set("sandwich_mode", 3) == QS_OK);
+    EXPECT(qs_tuning_set("gemm_fast", 0) == QS_OK && qs_tuning_set("sandwich_mode", 3) == QS_OK && qs_tuning_set("small4", 2) == QS_OK);
     EXPECT(qs_tuning_set("no_such_knob", 1) == QS_ERR_BAD_EXTENT && qs_tuning_set(nullptr, 1) == QS_ERR_NULL_POINTER);
     EXPECT(qs_tuning_reset() == QS_OK);
     EXPECT(qs_probe_mfma_f64(nullptr, 1, 1, nullptr) == QS_ERR_NULL_POINTER);

@@ -29,5 +29,8 @@ def test_native_host_program(tmp_path, L, M):
          f"-Wl,-rpath,{libdir}", "-o", exe],
         check=True, capture_output=True, timeout=300,
     )
-    res = subprocess.run([exe, str(L), str(M)], capture_output=True, text=True, timeout=600)
+    # (the sharded-rows call of the demo loads RCCL at run time: ROCm's library directory on the loader path)
+    env = dict(os.environ, LD_LIBRARY_PATH="/opt/rocm/lib:" + os.environ.get("LD_LIBRARY_PATH", ""))
+    res = subprocess.run([exe, str(L), str(M)], capture_output=True, text=True, timeout=600, env=env)
     assert res.returncode == 0 and "CABI_DEMO_OK" in res.stdout, res.stdout + res.stderr
+    assert "mixed_rel_err" in res.stdout and "sharded_rows=1" in res.stdout, res.stdout      # both round-3 entry points ran
