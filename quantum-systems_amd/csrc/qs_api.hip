@@ -218,6 +218,7 @@ int qs_tuning_set(const char* key, int64_t value) {
     if (!strcmp(key, "gemm_fast_shape")) { g_tune.gemm_fast_shape = (int)value; return QS_OK; }
     if (!strcmp(key, "gemm_pick")) { g_tune.gemm_pick = (int)value; return QS_OK; }
     if (!strcmp(key, "small4")) { g_tune.small4 = (int)value; return QS_OK; }
+    if (!strcmp(key, "pair4c")) { g_tune.pair4c = (int)value; return QS_OK; }
     if (!strcmp(key, "sandwich")) { g_tune.sandwich = (int)value; return QS_OK; }
     if (!strcmp(key, "sandwich_mode")) { g_tune.sandwich_mode = (int)value; return QS_OK; }
     if (!strcmp(key, "sandwich_t2")) { g_tune.sandwich_t2 = (int)value; return QS_OK; }
@@ -295,6 +296,19 @@ static int transform_two_body_impl(int in_dtype, int dtype, const void* u, const
         int rc1 = small4_try(dtype, u, WA, C, M, 1, C, 1, M, L * L, L, M, L * L, L, 1, MM, M, 1, 0, s);
         if (rc1 == QS_OK)
             rc1 = small4_try(dtype, WA, out, Ct, 1, L, Ct, L, 1, MM, L, M, 1, L * MM, MM, 1, M * MM, MM, 1, s);
+        if (rc1 != 1) return rc1;
+    }
+
+    // complex128 up to 56 orbitals: the same two passes with two items per matrix instruction (qs_pair4c.hip).  Automatic
+    // where it measured faster than the four 16-wide passes (same-box sweep, profiles/r03_pair4c.txt): 25 ... 47 orbitals,
+    // 1.02-1.25x; from 48 up the accumulators and B operands of its eight waves crowd out the prefetch of the next item pair
+    // and it falls behind (l = 55: 0.81x).  g_tune.pair4c == 2: wherever it exists.
+    if (in_dtype == dtype && dtype == QS_C128 && g_tune.pair4c && L <= 56 && M <= 56 && n4s == cdiv(M, 4) &&
+        (g_tune.pair4c == 2 || (n4s >= 7 && (n4s <= 11 || (n4s == 12 && L <= 47 && M <= 47))))) {
+        const int64_t MM = M * M;
+        int rc1 = pair4c_try(dtype, u, WA, C, M, 1, C, 1, M, L * L, L, M, L * L, L, 1, MM, M, 1, 0, s);
+        if (rc1 == QS_OK)
+            rc1 = pair4c_try(dtype, WA, out, Ct, 1, L, Ct, L, 1, MM, L, M, 1, L * MM, MM, 1, M * MM, MM, 1, s);
         if (rc1 != 1) return rc1;
     }
 

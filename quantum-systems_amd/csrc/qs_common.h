@@ -120,6 +120,11 @@ int small4_try(int dtype, const void* in, void* out, const void* R, int64_t r_sk
                int64_t l_sp, int64_t l_sa, int64_t nitems, int64_t L, int64_t M, int64_t in_item, int64_t in_row,
                int64_t in_col, int64_t out_item, int64_t out_row, int64_t out_col, int tensor_is_b, hipStream_t stream);
 
+// The same for complex128 up to 56 orbitals (qs_pair4c.hip): two items per matrix instruction, blocks = (item, re | im).
+int pair4c_try(int dtype, const void* in, void* out, const void* R, int64_t r_sk, int64_t r_sj, const void* Lm,
+               int64_t l_sp, int64_t l_sa, int64_t nitems, int64_t L, int64_t M, int64_t in_item, int64_t in_row,
+               int64_t in_col, int64_t out_item, int64_t out_row, int64_t out_col, int tensor_is_b, hipStream_t stream);
+
 // Short-and-wide streaming product (qs_gemm_skinny.hip): same return convention.
 int gemm_skinny_try(int dtype, const double* A, const double* B, double* C, int64_t m, int64_t n,
                     int64_t k, int64_t lda, int64_t ldb, int64_t ldc, int64_t batch, int accumulate,
@@ -159,6 +164,8 @@ struct Tuning {
     int sandwich_mode = -1;      // work split of the fused passes: -1 automatic, 0 one item quad per workgroup, 1 four adjacent quads, 3 + step barrier
     int small4 = 1;              // both fused passes of a basis of <= 32 orbitals on the LDS-staged 4-wide kernel (qs_small4.hip), fp64 and
                                  // complex128: 1 automatic (fp64 up to 16, complex128 up to 24 orbitals), 2 wherever it exists (up to 32), 0 off
+    int pair4c = 1;              // complex128 up to 56 orbitals: both fused passes on the two-items-per-instruction kernel (qs_pair4c.hip):
+                                 // 1 automatic, 2 wherever it exists, 0 off
     int sandwich = 1;            // 4-wide fused passes of a small-basis transform: 0 off, 1 both (d, c) and (b, a), 2 (d, c) only, 3 (b, a) only;
                                  // tuning runs, wherever the kernel exists (not only where it measured faster): 4 both, 5 (d, c) only, 6 (b, a) only
 };

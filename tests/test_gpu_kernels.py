@@ -170,6 +170,51 @@ def test_small_basis_kernel_is_bit_identical_to_the_16_wide_path(K, cplx):
     assert relerr(host(got), orc.transform_two_body(uu, Cn)) <= RTOL
 
 
+def test_complex_fused_kernel_is_bit_identical_to_the_16_wide_path(K):
+    # qs_pair4c.hip: both fused passes of a COMPLEX128 basis of up to 56 orbitals, two items per matrix instruction (blocks =
+    # (item, re | im)); the same chains of fused multiply-adds as the four 16-wide passes, element for element.
+    rng = np.random.default_rng(77)
+    shapes = [(25, 25), (28, 27), (29, 32), (33, 33), (36, 34), (37, 40), (41, 44), (47, 45), (48, 48), (49, 52), (55, 55), (56, 53)]
+    small = [(3, 3), (8, 6), (13, 16), (21, 24)]            # (qs_small4.hip is the automatic choice there)
+    for (L, M) in shapes + small:
+        u = dev(rng.standard_normal((L,) * 4) + 1j * rng.standard_normal((L,) * 4))
+        C = dev((rng.standard_normal((L, M)) + 1j * rng.standard_normal((L, M))) / np.sqrt(L))
+        Ct = dev((rng.standard_normal((M, L)) + 1j * rng.standard_normal((M, L))) / np.sqrt(L))
+        auto = 25 <= max(L, M) <= 47 and min(L, M) > 24
+        K.tuning_set("pair4c", 2)
+        K.tuning_set("small4", 0)
+        try:
+            got = K.transform_two_body(u, C, Ct)
+            ran = K.last_dispatch()
+        finally:
+            K.tuning_reset()
+        assert ran == f"qs::pair4c_kernel<{-(-L // 4)}> x2", (L, M, ran)
+        K.transform_two_body(u, C, Ct)
+        assert ("pair4c" in K.last_dispatch()) == auto, (L, M, K.last_dispatch())
+        K.tuning_set("pair4c", 0)
+        K.tuning_set("small4", 0)
+        try:
+            wide = K.transform_two_body(u, C, Ct)
+            assert "pair4c" not in K.last_dispatch() and "small4" not in K.last_dispatch()
+        finally:
+            K.tuning_reset()
+        assert torch.equal(got, wide), (L, M)
+    # an odd number of items (the last pair is half empty) next to poisoned memory
+    L = 5
+    big = torch.full((L + 1, L, L, L), float("nan"), dtype=torch.complex128, device="cuda")
+    uu = rng.standard_normal((L,) * 4) + 1j * rng.standard_normal((L,) * 4)
+    big[:L] = dev(uu)
+    Cn = rng.standard_normal((L, L)) + 1j * rng.standard_normal((L, L))
+    K.tuning_set("pair4c", 2)
+    K.tuning_set("small4", 0)
+    try:
+        got = K.transform_two_body(big[:L], dev(Cn))
+        assert "pair4c" in K.last_dispatch() and torch.isfinite(torch.view_as_real(got)).all()
+    finally:
+        K.tuning_reset()
+    assert relerr(host(got), orc.transform_two_body(uu, Cn)) <= RTOL
+
+
 def test_spf_golden(K, golden):
     g = golden("transform_spf")
     L = g["C"].shape[0]
