@@ -83,7 +83,7 @@ def parse(argv=None):
                          "[4] l=512 complex128 time-evolution pattern on per-rank slabs")
     ap.add_argument("--legs", default="replicated,rows,rows_rccl,rccl",
                     help="layouts measured by --layout auto at N > 1, in this order")
-    ap.add_argument("--leg-timeout", type=float, default=420.0, help="seconds before a leg is given up and killed")
+    ap.add_argument("--leg-timeout", type=float, default=300.0, help="seconds before a leg is given up and killed")
     ap.add_argument("--chunk-rows", type=int, default=0, help="input rows per exchange step of the rows layouts (0 = automatic)")
     ap.add_argument("--gather", action="store_true", help="make the all-gather of the result part of `value`")
     ap.add_argument("--no-gather-leg", action="store_true", help="skip the second, gather-inclusive timing leg at N > 1")

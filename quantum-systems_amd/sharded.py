@@ -418,7 +418,10 @@ def stream_chunk_rows(L, M, il_max, elem_bytes, budget_bytes=None):
     small: one exchange, today's out-of-place behaviour), at least one."""
     budget = STREAM_BUDGET_BYTES if budget_bytes is None else budget_bytes
     unit = max(L * L * M, L * M * M, M * M * M) * elem_bytes
-    return int(max(1, min(il_max, budget // (4 * unit))))
+    ni = int(max(1, min(il_max, budget // (6 * unit))))
+    if il_max >= 4:
+        ni = min(ni, -(-il_max // 4))                      # at least four steps: the exchange has products to hide under
+    return ni
 
 
 def transform_two_body_rows(rows, C, C_tilde=None, rank=0, world=1, group=None, engine=HipEngine, in_part=None,
@@ -448,7 +451,8 @@ def transform_two_body_rows(rows, C, C_tilde=None, rank=0, world=1, group=None, 
     received row that is still to be read.  Every sum runs over the same index in the same order as in the
     out-of-place layouts (d, c, the whole leading index, the sharded one): bit-identical results.
 
-    Peak memory: input rows + ``rows_buffer_elems`` (= result rows + one row when L = M) + 4 chunk_rows l^3.
+    Peak memory: input rows + ``rows_buffer_elems`` (= result rows + one row when L = M) + 6 chunk_rows l^3 (two send
+    blocks and two receive stagings: the exchange of a step overlaps the products of the next).
     ``out`` may supply the (flat) buffer to reuse it across steps of a time loop; the result is a view of it."""
     Ct = _bra(C, C_tilde)
     L, M = C.shape
@@ -477,14 +481,35 @@ def transform_two_body_rows(rows, C, C_tilde=None, rank=0, world=1, group=None, 
     nsteps = -(-il_max // ni)
     t1 = torch.empty(ni * L * L * M, dtype=dt, device=dev)
     t2 = torch.empty(ni * L * MM, dtype=dt, device=dev)
-    W = torch.empty(M * ni * MM, dtype=dt, device=dev)
-    stage = None
+    # The exchange of step t runs (asynchronously, on the backend's own stream) under the products of step t + 1: two send
+    # blocks and two receive stagings, the received rows are put in place one step late.  (On RCCL the C-ABI form does
+    # the same without staging: qs_transform_two_body_sharded_rows.)
+    nbuf_x = 2 if (world > 1 and nsteps > 1) else 1
+    Ws = [torch.empty(M * ni * MM, dtype=dt, device=dev) for _ in range(nbuf_x)]
+    stages = []
     if world > 1:
-        stage = torch.empty(jl * sum(min(ni, ipart.count(g)) for g in range(world)) * MM * width,
-                            dtype=torch.float64, device=dev)
+        n_stage = jl * sum(min(ni, ipart.count(g)) for g in range(world)) * MM * width
+        stages = [torch.empty(n_stage, dtype=torch.float64, device=dev) for _ in range(nbuf_x)]
+
+    def settle(pending):
+        """The received blocks of an earlier step into place: R[j'_loc][i_global][(r,s)]."""
+        work, recv, out_splits, counts, i0 = pending
+        work.wait()
+        off = 0
+        for g in range(world):
+            if out_splits[g]:
+                blk = recv[off: off + out_splits[g]]
+                if width == 2:
+                    blk = torch.view_as_complex(blk.reshape(-1, 2))
+                g0 = ipart.starts[g] + i0
+                R[:, g0:g0 + counts[g]].copy_(blk.reshape(jl, counts[g], MM))
+            off += out_splits[g]
+
+    pending = None
     for t in range(nsteps):
         i0 = t * ni
         n = max(0, min(ni, il - i0))
+        W = Ws[t % nbuf_x]
         if n > 0:
             src = rows[i0:i0 + n]
             if src.dtype != dt:
@@ -502,18 +527,14 @@ def transform_two_body_rows(rows, C, C_tilde=None, rank=0, world=1, group=None, 
             continue
         in_splits = [jpart.count(g) * n * MM * width for g in range(world)]
         out_splits = [jl * counts[g] * MM * width for g in range(world)]
-        recv = stage[:sum(out_splits)]
-        dist.all_to_all_single(recv, _as_real_flat(W[:M * n * MM]), out_splits, in_splits, group=group)
-        off = 0
-        for g in range(world):
-            if out_splits[g]:
-                blk = recv[off: off + out_splits[g]]
-                if width == 2:
-                    blk = torch.view_as_complex(blk.reshape(-1, 2))
-                g0 = ipart.starts[g] + i0
-                R[:, g0:g0 + counts[g]].copy_(blk.reshape(jl, counts[g], MM))
-            off += out_splits[g]
-    del t1, t2, W, stage
+        recv = stages[t % nbuf_x][:sum(out_splits)]
+        work = dist.all_to_all_single(recv, _as_real_flat(W[:M * n * MM]), out_splits, in_splits, group=group, async_op=True)
+        if pending is not None:
+            settle(pending)                                # step t - 1: done by now, or waited for here
+        pending = (work, recv, out_splits, counts, i0)
+    if pending is not None:
+        settle(pending)
+    del t1, t2, Ws, stages
     # I:  out[p][i', (r,s)] = Ct[i', i] R[p][i, (r,s)], packed from the start of the buffer
     for p in range(jl):
         engine.gemm_strided(dt, Ct, buf, buf, M, MM, L, L, MM, MM, b_off=r0 + p * L * MM, c_off=p * M * MM)
