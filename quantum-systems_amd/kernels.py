@@ -138,29 +138,34 @@ def default_bra(C):
 
 
 class Workspace:
-    """Grow-only device scratch shared by the transforms of one process.
+    """Grow-only device scratch shared by the transforms of one process, ONE BUFFER PER DEVICE (a process that drives
+    several GPUs -- the one-process-eight-devices style -- would otherwise free and re-allocate the scratch of the
+    other device on every call).
 
-    The C ABI never allocates; this keeps one buffer alive between calls so a
-    time loop calling the transform every step does not hit the allocator.
-    One buffer per process: calls that share it are meant to be issued on ONE
-    stream (stream order keeps them apart); concurrent streams should call the
-    C ABI with their own workspaces, or use one ``TransformPlan`` each."""
+    The C ABI never allocates; this keeps the buffers alive between calls so a time loop calling the transform every step
+    does not hit the allocator.  Calls that share a device's buffer are meant to be issued on ONE stream per device (stream
+    order keeps them apart); concurrent streams of one device should call the C ABI with their own workspaces, or use one
+    ``TransformPlan`` each."""
 
     def __init__(self):
-        self._buf = None
+        self._bufs = {}
 
     def get(self, nbytes, device):
-        if (
-            self._buf is None
-            or self._buf.numel() < nbytes
-            or self._buf.device != device
-        ):
-            self._buf = None  # release before growing
-            self._buf = torch.empty(int(nbytes), dtype=torch.uint8, device=device)
-        return self._buf
+        key = (device.type, device.index if device.index is not None else torch.cuda.current_device())
+        buf = self._bufs.get(key)
+        if buf is None or buf.numel() < nbytes:
+            self._bufs[key] = None  # release before growing
+            buf = torch.empty(int(nbytes), dtype=torch.uint8, device=device)
+            self._bufs[key] = buf
+        return buf
 
-    def release(self):
-        self._buf = None
+    def release(self, device=None):
+        """Drop the scratch of one device (or of all of them)."""
+        if device is None:
+            self._bufs.clear()
+        else:
+            device = torch.device(device)
+            self._bufs.pop((device.type, device.index if device.index is not None else torch.cuda.current_device()), None)
 
 
 workspace = Workspace()

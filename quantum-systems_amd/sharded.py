@@ -144,8 +144,8 @@ def _as_real_flat(t):
 def all_gather_slabs(out_slab, M, rank, world, group=None, full=None, part=None):
     """Replicate the p-sharded result: returns the full (M,M,M,M) tensor (the single
     all-gather of the north star).  Even slabs are gathered straight into the result
-    tensor (no staging copy); uneven slabs are padded to the largest.  ``full`` may
-    supply the result buffer."""
+    tensor (no staging copy); uneven slabs are broadcast one by one into their places
+    (no staging either).  ``full`` may supply the result buffer."""
     part = part or SlabPartition(M, world)
     if world == 1:
         return out_slab
@@ -158,15 +158,16 @@ def all_gather_slabs(out_slab, M, rank, world, group=None, full=None, part=None)
     if M % world == 0 and part.is_balanced():
         dist.all_gather_into_tensor(full_flat, flat, group=group)
         return full
-    biggest = max(part.count(r) for r in range(world)) * per_row * width
-    send = torch.zeros(biggest, dtype=torch.float64, device=out_slab.device)
-    send[: flat.numel()] = flat
-    recv = torch.empty(world * biggest, dtype=torch.float64, device=out_slab.device)
-    dist.all_gather_into_tensor(recv, send, group=group)
+    # uneven slabs: every rank's slab is broadcast straight into its place in the result (G collectives on contiguous
+    # views of `full`, no padded staging copy of the tensor on either side)
     for r in range(world):
         lo, hi = part.bounds(r)
-        n = (hi - lo) * per_row * width
-        full_flat[lo * per_row * width: lo * per_row * width + n] = recv[r * biggest: r * biggest + n]
+        if hi == lo:
+            continue
+        view = full_flat[lo * per_row * width: hi * per_row * width]
+        if r == rank:
+            view.copy_(flat)
+        dist.broadcast(view, src=dist.get_global_rank(group, r) if group is not None else r, group=group)
     return full
 
 
