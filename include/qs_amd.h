@@ -264,11 +264,17 @@ int qs_comm_world(void* comm);
 const char* qs_last_comm_error(void);
 
 /*
- * STATUS of the sharded entry points below: EXPERIMENTAL.  They have run on
- * hardware with ONE rank only (the development boxes hold one GPU); worlds of
- * 2..8 ranks are covered by CPU replays of their exchange plans
- * (qs_sharded_exchange_plan, qs_sharded_rows_exchange_plan) and by the same
- * algorithms driven through torch.distributed in the Python layer.
+ * STATUS of the sharded entry points below: EXPERIMENTAL.  On REAL RCCL they
+ * have run with ONE rank only (the development boxes hold one GPU).  Their
+ * multi-rank branches are executed by tests/test_gpu_mock_rccl_ranks.py: 2-5
+ * rank processes on one GPU, every ncclSend / ncclRecv the library posts
+ * carried by a file-based stand-in for librccl (tests/cabi/mock_rccl.cpp: same
+ * pairing and size rules, no asynchrony), results bit-identical to the
+ * single-GPU transform; in addition worlds of 1..8 ranks are covered by CPU
+ * replays of the exchange plans (qs_sharded_exchange_plan,
+ * qs_sharded_rows_exchange_plan) and by the same algorithms driven through
+ * torch.distributed in the Python layer.  Unrun until an 8-GPU node: RCCL's own
+ * transport and the overlap of the two streams.
  *
  * Four-index transform of a tensor sharded over the ranks of `comm`:
  *   u_bslab   : u[:, b_lo:b_hi, :, :]  (L, bl, L, L), this rank's share of the

@@ -22,6 +22,9 @@ typedef double f64x2 __attribute__((ext_vector_type(2)));
 // anti-symmetrisation: 5.41 -> 5.77 TB/s at l = 256; the spin expansion, whose lanes fill a line from
 // several instructions, LOSES 4 % with it and keeps plain stores).
 template <typename T> __device__ __forceinline__ void stream_store(T* p, T v) { __builtin_nontemporal_store(v, p); }
+#ifndef QS_SPIN_NT
+#define QS_SPIN_NT 0          // non-temporal stores in the spin-expansion / two-body S^2 kernels (A/B switch, profiles/r03_*)
+#endif
 
 static constexpr int PT = 32;        // tile edge (elements)
 static constexpr int PS = PT + 1;    // LDS row stride
@@ -116,7 +119,11 @@ __device__ __forceinline__ void spin_write_block(TO* __restrict__ o, int n2, con
             TI v = zero_of<TI>();
             if (s1 == s3 && s2 == s4) v = ta[rr][sc];
             if (as && s1 == s4 && s2 == s3) v = v - tb[sc][rr];
+#if QS_SPIN_NT
+            stream_store(&o[(int64_t)(2 * r + s3) * n2 + (2 * c + s4)], widen<TO, TI>(v));
+#else
             o[(int64_t)(2 * r + s3) * n2 + (2 * c + s4)] = widen<TO, TI>(v);
+#endif
         }
     }
 }
@@ -216,7 +223,11 @@ __global__ __launch_bounds__(1024) void spin2_tb_kernel(const f64x2* __restrict_
                 v = v + cmul(sp[k * n + r], qs[k]);
                 if (as) w = w + cmul(ps[k], sq[k * n + r]);
             }
+#if QS_SPIN_NT
+            stream_store(&o[(int64_t)r * n + s], as ? (v - w) : v);
+#else
             o[(int64_t)r * n + s] = as ? (v - w) : v;
+#endif
         }
     }
 }

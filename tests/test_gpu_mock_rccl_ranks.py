@@ -1,0 +1,61 @@
+"""The MULTI-RANK branches of the C ABI's sharded entry points, executed: several rank processes on this one GPU, the
+library's ncclSend / ncclRecv calls carried by a file-based stand-in for librccl (tests/cabi/mock_rccl.cpp: same pairing
+and size rules as RCCL, no asynchrony).  Each rank is the plain C++ program tests/cabi/sharded_ranks_demo.cpp (no Python,
+no torch in the process, so the library's dlopen finds the stand-in): qs_transform_two_body_sharded_rows for leading-index
+rows (balanced and spin-doubled partitions: bit-identical to the single-GPU transform), second-index rows, a real tensor
+against complex coefficients, and the round-2 entry qs_transform_two_body_sharded.  What stays unrun until the driver's
+8-GPU node: real RCCL and the overlap of its streams."""
+
+import os
+import shutil
+import subprocess
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def built(tmp_path_factory):
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        pytest.skip("no hipcc on this box")
+    libdir = os.path.join(ROOT, "quantum-systems_amd")
+    assert os.path.exists(os.path.join(libdir, "libqs_amd.so")), "build the library first (__graft_entry__.build)"
+    d = tmp_path_factory.mktemp("mock_rccl")
+    mock = d / "librccl.so.1"
+    subprocess.run([hipcc, "-O1", "-std=c++17", "--offload-arch=gfx950", "-fPIC", "-shared",
+                    os.path.join(ROOT, "tests", "cabi", "mock_rccl.cpp"), "-o", str(mock)], check=True, capture_output=True, timeout=300)
+    exe = d / "sharded_ranks_demo"
+    subprocess.run([hipcc, "-O2", "-std=c++17", "--offload-arch=gfx950", "-I", os.path.join(ROOT, "include"),
+                    os.path.join(ROOT, "tests", "cabi", "sharded_ranks_demo.cpp"), "-L", libdir, "-l:libqs_amd.so",
+                    f"-Wl,-rpath,{libdir}", "-o", str(exe)], check=True, capture_output=True, timeout=300)
+    return d, str(exe)
+
+
+@pytest.mark.parametrize("world,L,M,mode,chunk", [
+    (2, 12, 12, 0, 2), (3, 14, 9, 1, 1), (2, 10, 14, 1, 3), (3, 16, 16, 2, 0), (4, 18, 18, 0, 1), (2, 40, 40, 1, 0),
+    (5, 6, 6, 0, 1),              # more ranks than some partitions have rows (2 x 3 spatial rows doubled: ranks with no rows)
+])
+def test_sharded_entry_points_with_several_ranks_on_one_device(built, world, L, M, mode, chunk):
+    d, exe = built
+    run_dir = d / f"run_{world}_{L}_{M}_{mode}_{chunk}"
+    run_dir.mkdir()
+    env = dict(os.environ, LD_LIBRARY_PATH=f"{d}:" + os.environ.get("LD_LIBRARY_PATH", ""), QS_MOCK_RCCL_DIR=str(run_dir))
+    idfile = str(run_dir / "unique_id")
+    procs = [subprocess.Popen([exe, str(r), str(world), idfile, str(L), str(M), str(mode), str(chunk)], env=env,
+                              stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for r in range(world)]
+    outs = []
+    try:
+        for p in procs:
+            out, _ = p.communicate(timeout=300)
+            outs.append(out)
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()                  # exactly the processes started above
+    text = "".join(outs)
+    assert all(p.returncode == 0 for p in procs), text
+    assert text.count("RANK_OK") == world, text
+    assert "mock rccl" not in text, text          # no complaint of the transport (sizes of every pair agreed)
