@@ -249,6 +249,9 @@ int qs_tdho_coulomb_elements_nm(void* out, const void* nm_table, int64_t l,
  *   most recent QS_ERR_COMM.
  * RCCL is loaded at run time (librccl.so.1; the copy already in the process
  * when there is one): single-GPU users have no link-time dependency on it.
+ * (Development / test hook: the environment variable QS_AMD_RCCL_LIB names a
+ * library to load instead -- the test suite's file-based stand-in, which lets
+ * several ranks share one GPU.)
  */
 #define QS_UNIQUE_ID_BYTES 128
 int qs_comm_unique_id(void* id /* QS_UNIQUE_ID_BYTES */);

@@ -22,6 +22,7 @@
 
 #include <dlfcn.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <memory>
@@ -65,9 +66,14 @@ const Rccl& rccl() {
     static const Rccl lib = [] {
         Rccl r;
         const char* names[] = {"librccl.so.1", "librccl.so"};
+        // development / test hook: QS_AMD_RCCL_LIB names the library to load instead (the file-based stand-in of
+        // tests/cabi/mock_rccl.cpp, which lets several ranks share one GPU, also inside a process that has PyTorch's RCCL)
+        if (const char* forced = getenv("QS_AMD_RCCL_LIB")) {
+            if (forced[0]) r.handle = dlopen(forced, RTLD_NOW | RTLD_LOCAL);
+        }
         for (const char* n : names) {      // a copy that is already in the process (PyTorch's) first
-            r.handle = dlopen(n, RTLD_NOW | RTLD_NOLOAD);
             if (r.handle) break;
+            r.handle = dlopen(n, RTLD_NOW | RTLD_NOLOAD);
         }
         for (const char* n : names) {
             if (r.handle) break;

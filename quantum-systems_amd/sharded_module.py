@@ -214,8 +214,13 @@ class ShardedDeviceModule(DeviceModule):
 
             box = [RcclComm.unique_id() if self.rank == 0 else None]
             if self.world > 1:
-                dist.broadcast_object_list(box, src=dist.get_global_rank(self.group, 0) if self.group else 0,
-                                           group=self.group)
+                if dist.get_backend(self.group) == "nccl":
+                    with torch.cuda.device(self.device):
+                        dist.broadcast_object_list(box, src=dist.get_global_rank(self.group, 0) if self.group else 0,
+                                                   group=self.group)
+                else:
+                    dist.broadcast_object_list(box, src=dist.get_global_rank(self.group, 0) if self.group else 0,
+                                               group=self.group, device=torch.device("cpu"))
             with torch.cuda.device(self.device):
                 self._rccl = RcclComm(self.rank, self.world, box[0])
         return self._rccl

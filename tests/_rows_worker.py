@@ -94,6 +94,23 @@ def main():
     assert np.abs(back.local.cpu().numpy() - u[back.lo:back.hi]).max() <= 1e-9 * np.abs(u).max()      # unitary round trip
     assert np.abs(one.gather().cpu().numpy() - ref).max() <= 1e-10 * np.abs(ref).max()
     assert np.abs(one.reshard(0).local.cpu().numpy() - ref[one.reshard(0).lo:one.reshard(0).hi]).max() <= 1e-10 * np.abs(ref).max()
+    if os.environ.get("QS_ROWS_WORKER_RCCL") == "1":
+        # the same through the module's own communicator: ONE C-ABI call per transform on every rank (the transport is the
+        # test suite's stand-in for librccl, QS_AMD_RCCL_LIB: real RCCL wants one GPU per rank)
+        cmod = qsa.ShardedDeviceModule(rank, world, device="cuda:0", exchange="rccl")
+        tc = cmod.shard(u)
+        onec = qsa.BasisSet.transform_two_body_elements(tc, cmod.asarray(C), cmod)
+        assert cmod.rccl() is not None and "rccl grouped send/recv" in K.last_dispatch(), K.last_dispatch()
+        assert onec.axis == 1 and torch.equal(onec.rows, one.rows)            # the same sums in the same order
+        backc = qsa.BasisSet.transform_two_body_elements(onec, cmod.asarray(C.conj().T.copy()), cmod)
+        assert backc.axis == 0 and np.abs(backc.local.cpu().numpy() - u[backc.lo:backc.hi]).max() <= 1e-9 * np.abs(u).max()
+        # a real tensor against complex coefficients stays real on its way in
+        ur = rng.standard_normal((L,) * 4)
+        outr = qsa.BasisSet.transform_two_body_elements(cmod.shard(ur), cmod.asarray(C), cmod)
+        refr = orc.transform_two_body(ur, C)
+        assert np.abs(outr.local.cpu().numpy() - refr[:, outr.lo:outr.hi]).max() <= 1e-10 * np.abs(refr).max()
+        cmod.rccl().close()
+        print(f"rank {rank}/{world} module on the C entry")
     dist.barrier()
     dist.destroy_process_group()
     print(f"rank {rank}/{world} ok")

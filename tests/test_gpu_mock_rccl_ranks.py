@@ -59,3 +59,43 @@ def test_sharded_entry_points_with_several_ranks_on_one_device(built, world, L, 
     assert all(p.returncode == 0 for p in procs), text
     assert text.count("RANK_OK") == world, text
     assert "mock rccl" not in text, text          # no complaint of the transport (sizes of every pair agreed)
+
+
+def test_bench_rccl_legs_with_two_ranks_over_the_stand_in(built):
+    # bench.py's two RCCL legs (the whole step ONE C-ABI call per rank), two ranks on this one GPU: the unique id broadcast
+    # over the job's process group, the communicator, the timed steps, the parity property summed over the ranks
+    import json
+    import sys
+
+    d, _ = built
+    for layout in ("rows_rccl", "rccl"):
+        run_dir = d / f"bench_{layout}"
+        run_dir.mkdir()
+        env = dict(os.environ, QS_BENCH_SINGLE_DEVICE="1", QS_BENCH_BACKEND="gloo", MASTER_ADDR="127.0.0.1",
+                   QS_AMD_RCCL_LIB=str(d / "librccl.so.1"), QS_MOCK_RCCL_DIR=str(run_dir))
+        for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT"):
+            env.pop(k, None)
+        cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+               "--orbitals", "48", "--layout", layout, "--no-cpu-baseline", "--no-probes", "--chunk-rows", "6"]
+        res = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=ROOT, env=env)
+        assert res.returncode == 0, res.stdout[-1000:] + res.stderr[-3000:]
+        line = json.loads([ln for ln in res.stdout.splitlines() if ln.strip().startswith("{")][0])
+        assert line["n_gpus"] == 2 and line["n_ranks_seen"] == 2 and line["parity"]["ok"] is True
+        assert "rccl grouped send/recv" in line["roofline"]["dispatch"]
+
+
+def test_sharded_module_through_the_c_entry_with_three_ranks(built):
+    # ShardedDeviceModule(exchange="rccl"): the API-level sharded transform is ONE C-ABI call per tensor on every rank
+    # (tests/_rows_worker.py with QS_ROWS_WORKER_RCCL=1: three ranks on this GPU, gloo for the process group)
+    import sys
+
+    d, _ = built
+    run_dir = d / "module_rccl"
+    run_dir.mkdir()
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", QS_ROWS_WORKER_RCCL="1",
+               QS_AMD_RCCL_LIB=str(d / "librccl.so.1"), QS_MOCK_RCCL_DIR=str(run_dir))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=3", "--master-addr", "127.0.0.1",
+           "--master-port", "29599", os.path.join(ROOT, "tests", "_rows_worker.py")]
+    res = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=900)
+    assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-4000:]
+    assert res.stdout.count(" ok") == 3 and res.stdout.count("module on the C entry") == 3
