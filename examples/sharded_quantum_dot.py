@@ -52,14 +52,16 @@ def main():
 
     h_dw = get_double_well_one_body_elements(l, 1.0, 1.0, 2.0, dtype=np.complex128, axis=0)
     _, C = np.linalg.eigh(h_dw)
-    system.change_basis(mod.asarray(C))                       # one all-to-all; u is now sharded over its second index
-    gos = system.construct_general_orbital_system()           # slab-local; the spatial slab is shared, not copied
+    system.change_basis(mod.asarray(C))                       # streamed transform; u is now sharded over its second index
+    gos = system.construct_general_orbital_system()           # the doubling wants leading-index rows: one all-to-all of the
+                                                              # (16x smaller) spatial tensor, then slab-local
     e = complex(gos.compute_reference_energy())
     f = torch.as_tensor(gos.construct_fock_matrix(gos.h, gos.u))
     u = gos.u
     if rank == 0:
-        print(f"{world} rank(s), {l} orbitals -> {gos.l} spin orbitals; this rank holds u[:, {u.lo}:{u.hi}] "
-              f"= {tuple(u.local.shape)} of {tuple(u.shape)} ({u.local.numel() * 16 / 1e6:.1f} MB)")
+        held = f"u[{u.lo}:{u.hi}]" if u.axis == 0 else f"u[:, {u.lo}:{u.hi}]"
+        print(f"{world} rank(s), {l} orbitals -> {gos.l} spin orbitals; this rank holds {held} "
+              f"= {tuple(u.local.shape)} of {tuple(u.shape)} ({u.rows.numel() * 16 / 1e6:.1f} MB)")
         print(f"reference energy {e.real:.8f}, Fock matrix {tuple(f.shape)}, lowest diagonal element "
               f"{float(f.diagonal().real.min()):.6f}, last kernels: {kernels.last_dispatch()}")
     dist.barrier()
