@@ -92,9 +92,11 @@ int matmul_real_by_complex(const void* A, const void* B, void* out, int64_t m, i
                            int64_t ldb, int64_t ldc, hipStream_t stream);
 
 // VALU-free fast path, exact and edge forms (qs_gemm_fast.hip): QS_OK / error after launching, 1 = not eligible.
+// general_cost: the general kernel's estimated time for this product (its best shape, in this kernel's units): the edge
+// form runs when its own estimate is not worse.
 int gemm_fast_try(int dtype, const double* A, const double* B, double* C, int64_t m, int64_t n,
                   int64_t k, int64_t lda, int64_t ldb, int64_t ldc, int64_t batch, int64_t sa,
-                  int64_t sb, int64_t sc, int accumulate, int group_along_m, hipStream_t stream);
+                  int64_t sb, int64_t sc, int accumulate, int group_along_m, double general_cost, hipStream_t stream);
 
 // Small-coefficient streaming product, m, k <= 64 (qs_gemm_stream.hip): same return convention.
 int gemm_stream_try(int dtype, const double* A, const double* B, double* C, int64_t m, int64_t n,

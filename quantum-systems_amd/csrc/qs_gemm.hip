@@ -389,7 +389,7 @@ struct TileShape { int id, bm, bn; double weight; };
 // work of a tile over its relative rate.  For a long list that is the padded area, as before; for a short one -- the
 // single-particle functions of a 55-orbital dot on a 101 x 101 grid are a 55 x 10201 product: 80 tiles of 64 x 128 --
 // it prefers tiles that fill the chip (g_tune.gemm_pick == 0: padded area only, the round-1 rule).
-static int pick_shape(const TileShape* cand, int ncand, int64_t m, int64_t n, int64_t batch) {
+static int pick_shape(const TileShape* cand, int ncand, int64_t m, int64_t n, int64_t batch, double* cost_out = nullptr) {
     int best = cand[0].id;
     double best_cost = 1e300;
     const double slots = 2.0 * device_cu_count();
@@ -400,8 +400,12 @@ static int pick_shape(const TileShape* cand, int ncand, int64_t m, int64_t n, in
         const double cost = rounds * area / cand[i].weight;
         if (cost < best_cost) { best_cost = cost; best = cand[i].id; }
     }
+    if (cost_out) *cost_out = best_cost;
     return best;
 }
+
+// full-tile rate of this kernel relative to the VALU-free one (l = 256: 59.6 against 67 TFLOP/s)
+constexpr double kGeneralRelativeRate = 0.89;
 
 template <int MODE>
 static int dispatch_f64(int cfg, const GemmArgs& g, int64_t batch, hipStream_t s) {
@@ -438,14 +442,15 @@ int gemm_f64(const double* A, const double* B, double* C, int64_t m, int64_t n, 
         if (rc != 1) return rc;
         rc = gemm_stream_try(QS_F64, A, B, C, m, n, k, lda, ldb, ldc, batch, sa, sb, sc, accumulate, stream);
         if (rc != 1) return rc;
-        rc = gemm_fast_try(QS_F64, A, B, C, m, n, k, lda, ldb, ldc, batch, sa, sb, sc,
-                           accumulate, g.group_along_m, stream);
-        if (rc != 1) return rc;
         static const TileShape cand[] = {
             {1, 128, 128, 1.00}, {12, 96, 128, 0.98}, {13, 128, 96, 0.98}, {8, 96, 96, 0.96},
             {5, 64, 64, 0.95},   {9, 128, 64, 0.90},  {10, 64, 128, 0.90}, {11, 32, 32, 0.73},
         };
-        cfg = pick_shape(cand, sizeof(cand) / sizeof(cand[0]), m, n, batch);
+        double cost = 0.0;
+        cfg = pick_shape(cand, sizeof(cand) / sizeof(cand[0]), m, n, batch, &cost);
+        rc = gemm_fast_try(QS_F64, A, B, C, m, n, k, lda, ldb, ldc, batch, sa, sb, sc,
+                           accumulate, g.group_along_m, cost / kGeneralRelativeRate, stream);
+        if (rc != 1) return rc;
     }
     return vec ? dispatch_f64<MODE_F64_VEC2>(cfg, g, batch, stream)
                : dispatch_f64<MODE_F64_SCALAR>(cfg, g, batch, stream);
@@ -464,7 +469,7 @@ int gemm_c128(const double* A, const double* B, double* C, int64_t m, int64_t n,
         rc = gemm_stream_try(QS_C128, A, B, C, m, n, k, lda, ldb, ldc, batch, sa, sb, sc, accumulate, stream);
         if (rc != 1) return rc;
         rc = gemm_fast_try(QS_C128, A, B, C, m, n, k, lda, ldb, ldc, batch, sa, sb, sc,
-                           accumulate, g.group_along_m, stream);
+                           accumulate, g.group_along_m, 0.0, stream);
         if (rc != 1) return rc;
         static const TileShape cand[] = {
             {1, 64, 128, 1.00}, {2, 128, 64, 1.00}, {6, 64, 64, 1.00}, {9, 96, 96, 0.97},

@@ -42,6 +42,8 @@
 
 #include <type_traits>
 
+#include <cmath>
+
 #include "qs_common.h"
 
 // Epilogue stores are non-temporal: the product's output is read again only by the NEXT contraction, after the
@@ -521,20 +523,31 @@ static int launch_fast(const double* A, const double* B, double* C, int64_t m, i
 
 namespace {
 struct FastShape { int id, tm, tn; double weight; };
-// relative full-tile rates of the edge-form shapes (profiles/r01_gemm_notes.txt)
-const FastShape kF64Shapes[] = {{1, 4, 4, 1.00}, {2, 2, 4, 0.93}, {3, 4, 2, 0.93}, {4, 2, 2, 0.85}};
+// Edge-form shapes: BM = 32 tm rows (any tm: two waves of 16 tm rows each), BN = 32 tn columns with tn a power of two (the
+// B stage is handed out row-wise to the 256 threads).  Round 3 added the tall-and-narrow shapes 5-9: in the c, b and a
+// contractions the NEW basis size M is the m extent of the product, and 128-row tiles waste up to half of the matrix pipe
+// on bases just above a multiple of 128 (l = 130: 256 rows for 130; with tm = 5: 160); the 2-D oscillator shells (66, 78,
+// 91, 105, 120, 136, 153, 171, 190, 210 ...) are such sizes.  Weights: relative full-tile rates (shapes 1-4 measured in
+// round 1, profiles/r01_gemm_notes.txt; 5-9 from the round-3 sweep, profiles/r03_mid_size_shapes.txt).
+const FastShape kF64Shapes[] = {{1, 4, 4, 1.00}, {2, 2, 4, 0.93}, {3, 4, 2, 0.93}, {4, 2, 2, 0.85}, {5, 3, 4, 0.91},
+                                {6, 5, 2, 0.92}, {7, 6, 2, 0.89}, {8, 7, 2, 0.92}, {9, 3, 2, 0.87}};
 const FastShape kC128Shapes[] = {{1, 4, 2, 1.00}, {2, 2, 4, 1.00}, {3, 2, 2, 0.95}};
 
+// Shape of the smallest estimated time -- rounds of the tile list over the resident workgroups (two per CU) times the
+// work of a tile over its relative rate (the rule of the general kernel, qs_gemm.hip pick_shape) -- and that estimate.
 template <size_t N>
-int pick_fast_shape(const FastShape (&cand)[N], int64_t m, int64_t n) {
-    if (g_tune.gemm_fast_shape >= 1 && g_tune.gemm_fast_shape <= (int)N) return g_tune.gemm_fast_shape;
+int pick_fast_shape(const FastShape (&cand)[N], int64_t m, int64_t n, int64_t batch, double* cost_out) {
+    const double slots = 2.0 * device_cu_count();
     int best = cand[0].id;
     double best_cost = 1e300;
     for (const FastShape& c : cand) {
-        const double padded = (double)(cdiv(m, 32 * c.tm) * 32 * c.tm) * (double)(cdiv(n, 32 * c.tn) * 32 * c.tn);
-        const double cost = padded / c.weight;
+        if (g_tune.gemm_fast_shape >= 1 && g_tune.gemm_fast_shape <= (int)N && c.id != g_tune.gemm_fast_shape) continue;
+        const double tiles = (double)cdiv(m, 32 * c.tm) * (double)cdiv(n, 32 * c.tn) * (double)batch;
+        const double rounds = tiles > 8 * slots ? tiles / slots : ceil(tiles / slots);
+        const double cost = rounds * (32.0 * c.tm) * (32.0 * c.tn) / c.weight;
         if (cost < best_cost) { best_cost = cost; best = c.id; }
     }
+    if (cost_out) *cost_out = best_cost;
     return best;
 }
 }  // namespace
@@ -543,7 +556,7 @@ int pick_fast_shape(const FastShape (&cand)[N], int64_t m, int64_t n) {
 // (caller falls back to the general kernel).
 int gemm_fast_try(int dtype, const double* A, const double* B, double* C, int64_t m, int64_t n,
                   int64_t k, int64_t lda, int64_t ldb, int64_t ldc, int64_t batch, int64_t sa,
-                  int64_t sb, int64_t sc, int accumulate, int group_along_m, hipStream_t stream) {
+                  int64_t sb, int64_t sc, int accumulate, int group_along_m, double general_cost, hipStream_t stream) {
     if (!g_tune.gemm_fast) return 1;
     const bool cx = dtype == QS_C128;
     const int64_t esz = cx ? 16 : 8;
@@ -568,26 +581,34 @@ int gemm_fast_try(int dtype, const double* A, const double* B, double* C, int64_
         if (m % 128 == 0 && n % 64 == 0) QS_FAST(true, 4, 2, true, false);
         if (m % 64 == 0 && n % 64 == 0) QS_FAST(true, 2, 2, true, false);
     }
-    // ---- edge form.  Measured on MI355X against the general kernel (profiles/r01_gemm_notes.txt):
-    // +3...9 % for fp64 products whose m and n are both >= 100 (l = 100, 160, 192, 200), slower
-    // below that (short tile lists: the general kernel's small and 96-wide shapes win) and for
-    // complex128 (whose general kernel is already light on VALU work per MFMA).
+    // ---- edge form.  Round 1 measured it against the general kernel with the four shapes of that time: +3...9 % for fp64
+    // products whose m and n are both >= 100, slower below (short tile lists: the general kernel's small and 96-wide shapes
+    // won) and for complex128 (whose general kernel is already light on VALU work per MFMA).  With the tall shapes the
+    // rule is an estimate: the edge form runs when its best shape's estimated time beats the general kernel's best
+    // (`general_cost`, same formula, scaled by the general kernel's full-tile rate relative to this one).
     // g_tune.gemm_fast: 1 = that policy, 3 = edge form wherever it applies (tests, tuning).
     if (g_tune.gemm_fast != 1 && g_tune.gemm_fast != 3) return 1;
-    if (g_tune.gemm_fast == 1 && (cx || m < 100 || n < 100)) return 1;
     if (cx) {
-        switch (pick_fast_shape(kC128Shapes, m, n)) {
+        if (g_tune.gemm_fast == 1) return 1;
+        switch (pick_fast_shape(kC128Shapes, m, n, batch, nullptr)) {
             case 1: QS_FAST(true, 4, 2, true, true);
             case 2: QS_FAST(true, 2, 4, true, true);
             default: QS_FAST(true, 2, 2, true, true);
         }
     }
-    const int shape = pick_fast_shape(kF64Shapes, m, n);
+    double cost = 0.0;
+    const int shape = pick_fast_shape(kF64Shapes, m, n, batch, &cost);
+    if (g_tune.gemm_fast == 1 && !(cost <= general_cost)) return 1;
     if (vec) {
         switch (shape) {
             case 1: QS_FAST(false, 4, 4, true, true);
             case 2: QS_FAST(false, 2, 4, true, true);
             case 3: QS_FAST(false, 4, 2, true, true);
+            case 5: QS_FAST(false, 3, 4, true, true);
+            case 6: QS_FAST(false, 5, 2, true, true);
+            case 7: QS_FAST(false, 6, 2, true, true);
+            case 8: QS_FAST(false, 7, 2, true, true);
+            case 9: QS_FAST(false, 3, 2, true, true);
             default: QS_FAST(false, 2, 2, true, true);
         }
     }
@@ -595,6 +616,11 @@ int gemm_fast_try(int dtype, const double* A, const double* B, double* C, int64_
         case 1: QS_FAST(false, 4, 4, false, true);
         case 2: QS_FAST(false, 2, 4, false, true);
         case 3: QS_FAST(false, 4, 2, false, true);
+        case 5: QS_FAST(false, 3, 4, false, true);
+        case 6: QS_FAST(false, 5, 2, false, true);
+        case 7: QS_FAST(false, 6, 2, false, true);
+        case 8: QS_FAST(false, 7, 2, false, true);
+        case 9: QS_FAST(false, 3, 2, false, true);
         default: QS_FAST(false, 2, 2, false, true);
     }
 #undef QS_FAST

@@ -525,7 +525,7 @@ def test_edge_form_product_vs_oracle(K, m, n, k, batch, cplx):
     try:
         K.tuning_set("gemm_fast", 0)
         general = host(K.matmul(dev(A), dev(B)))
-        for shape in (0, 1, 2, 3, 4):
+        for shape in (0, 1, 2, 3, 4, 5, 6, 7, 8, 9):
             K.tuning_set("gemm_fast", 3)
             K.tuning_set("gemm_fast_shape", shape)
             got = host(K.matmul(dev(A), dev(B)))
