@@ -254,11 +254,14 @@ void gemm_kernel(const GemmArgs g) {
         for (int t = 0; t < nk; ++t) {
             const int cur = t & 1;
             if (t + 1 < nk) fetch((t + 1) * KT);
+            const int ks_live = t + 1 < nk ? KS : (K - t * KT + 3) / 4;     // (the last stage's k-steps beyond K multiply zeros)
 #pragma unroll
             for (int kk = 0; kk < KS; ++kk) {
-                double af[NP][TM], bf[NP][TN];
-                read_frags(cur, kk, af, bf);
-                mfma_step(af, bf);
+                if (kk < ks_live) {
+                    double af[NP][TM], bf[NP][TN];
+                    read_frags(cur, kk, af, bf);
+                    mfma_step(af, bf);
+                }
             }
             if (t + 1 < nk) stash(cur ^ 1, (t + 1) * KT);
             __syncthreads();
@@ -275,13 +278,17 @@ void gemm_kernel(const GemmArgs g) {
         read_frags(0, 0, a0, b0);
         auto stage = [&](int t, auto do_stash, auto do_fetch, auto do_next) {
             const int cur = t & 1;
+            // the last stage's k-steps beyond K multiply zeros: skipped (wave-uniform branches around the MFMAs only; adding
+            // 0 . 0 never changed a value, so the results are the same bits)
+            constexpr bool last = !decltype(do_stash)::value;
+            const int ks_live = last ? (K - t * KT + 3) / 4 : KS;
 #pragma unroll
             for (int kk = 0; kk + 1 < KS; ++kk) {
                 // the fence keeps the fragment reads of step kk+1 AHEAD of the
                 // MFMAs of step kk (the compiler otherwise sinks them behind the
                 // MFMA cluster and every k-step pays the LDS latency)
-                if ((kk & 1) == 0) { read_frags(cur, kk + 1, a1, b1); __builtin_amdgcn_sched_barrier(0); mfma_step(a0, b0); }
-                else               { read_frags(cur, kk + 1, a0, b0); __builtin_amdgcn_sched_barrier(0); mfma_step(a1, b1); }
+                if ((kk & 1) == 0) { read_frags(cur, kk + 1, a1, b1); __builtin_amdgcn_sched_barrier(0); if (!last || kk < ks_live) mfma_step(a0, b0); }
+                else               { read_frags(cur, kk + 1, a0, b0); __builtin_amdgcn_sched_barrier(0); if (!last || kk < ks_live) mfma_step(a1, b1); }
                 __builtin_amdgcn_sched_barrier(0);
             }
             if constexpr (decltype(do_stash)::value) stash(cur ^ 1, (t + 1) * KT);
@@ -290,7 +297,7 @@ void gemm_kernel(const GemmArgs g) {
             // KS is even: the last k-step lives in (a1, b1); (a0, b0) is free again
             if constexpr (decltype(do_next)::value) read_frags(cur ^ 1, 0, a0, b0);
             __builtin_amdgcn_sched_barrier(0);
-            mfma_step(a1, b1);
+            if (!last || KS - 1 < ks_live) mfma_step(a1, b1);
             __builtin_amdgcn_sched_barrier(0);
         };
         using T_ = std::true_type;
