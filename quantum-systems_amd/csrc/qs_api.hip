@@ -211,6 +211,7 @@ int qs_tuning_set(const char* key, int64_t value) {
     if (!strcmp(key, "gemm_c128_cfg")) { g_tune.gemm_c128_cfg = (int)value; return QS_OK; }
     if (!strcmp(key, "gemm_pipe")) { g_tune.gemm_pipe = (int)value; return QS_OK; }
     if (!strcmp(key, "gemm_fast")) { g_tune.gemm_fast = (int)value; return QS_OK; }
+    if (!strcmp(key, "gemm_fit")) { g_tune.gemm_fit = (int)value; return QS_OK; }
     if (!strcmp(key, "gemm_skinny")) { g_tune.gemm_skinny = (int)value; return QS_OK; }
     if (!strcmp(key, "gemm_stream")) { g_tune.gemm_stream = (int)value; return QS_OK; }
     if (!strcmp(key, "slab_pair")) { g_tune.slab_pair = (int)value; return QS_OK; }

@@ -157,6 +157,8 @@ struct Tuning {
     int gemm_fast_persist = 1;   // 0 one workgroup per tile, 1 automatic, 2 always persistent, >= 3 tiles per workgroup
     int gemm_pick = 1;           // tile shape of the general kernel: 1 by rounds over the resident workgroups x tile work, 0 by padded area
     int gemm_fast_shape = 0;     // forces edge-form shape 1..N (0 = by padded-work cost)
+    int gemm_fit = 1;            // fitted tile shapes of the general kernel (the basis size covered by one tile, to the next multiple of
+                                 // 16): 1 by estimated time, 2 wherever they exist, 0 off
     int gemm_skinny = 1;         // 0 disables the short-and-wide streaming product
     int gemm_stream = 1;         // 0 disables the small-coefficient streaming product, 2 = never split rows over two waves
     int slab_pair = 1;           // 0 disables the fused (d, c) pass, 2 = one wave per slab always

@@ -357,8 +357,10 @@ static int launch_one(GemmArgs g, int64_t batch, hipStream_t stream) {
     constexpr bool pipe_fits = !((MODE == MODE_F64_SCALAR && TM * TN >= 16) ||
                                  (MODE == MODE_C128 && TM * TN >= 9) || WM * WN != 4 || WM != WN);
     const int pipe = (g_tune.gemm_pipe && pipe_fits) ? 1 : 0;
-    auto kern = pipe ? gemm_kernel<WM, WN, TM, TN, KT, MODE, true>
-                     : gemm_kernel<WM, WN, TM, TN, KT, MODE, false>;
+    auto kern = gemm_kernel<WM, WN, TM, TN, KT, MODE, false>;
+    if constexpr (pipe_fits) {        // (the rotated form is only instantiated where it can run: the fitted shapes below are many)
+        if (pipe) kern = gemm_kernel<WM, WN, TM, TN, KT, MODE, true>;
+    }
     if (int rc = opt_in_dynamic_lds((const void*)kern, lds, lds_opt_in[pipe], "hipFuncSetAttribute(gemm)")) return rc;
     hipLaunchKernelGGL(kern, dim3((unsigned)nwg), dim3(64 * WM * WN), lds, stream, g);
     note_dispatch("qs::gemm_kernel<%d, %d, %d, %d, %d, %d, %s>", WM, WN, TM, TN, KT, MODE, pipe ? "true" : "false");
@@ -413,6 +415,10 @@ static int pick_shape(const TileShape* cand, int ncand, int64_t m, int64_t n, in
 
 // full-tile rate of this kernel relative to the VALU-free one (l = 256: 59.6 against 67 TFLOP/s)
 constexpr double kGeneralRelativeRate = 0.89;
+// relative rate of the fitted shapes (plain schedule, a quarter-wide wave tile): profiles/r03_mid_size_shapes.txt
+constexpr double kFitWeight = 0.80;      // (measured on 8-byte staging, in units of this kernel's 128 x 128 tile on 16-byte staging)
+// 8-byte staging (odd extents or strides) against 16-byte staging, both tiled kernels
+constexpr double kScalarStagingRate = 0.88;
 
 template <int MODE>
 static int dispatch_f64(int cfg, const GemmArgs& g, int64_t batch, hipStream_t s) {
@@ -430,7 +436,26 @@ static int dispatch_f64(int cfg, const GemmArgs& g, int64_t batch, hipStream_t s
         case 11: return launch_one<2, 2, 1, 1, 16, MODE>(g, batch, s);   //  32 x  32
         case 12: return launch_one<2, 2, 3, 4, 16, MODE>(g, batch, s);   //  96 x 128
         case 13: return launch_one<2, 2, 4, 3, 16, MODE>(g, batch, s);   // 128 x  96
-        default: return QS_ERR_BAD_EXTENT;
+        default: break;
+    }
+    // FITTED shapes (round 3): the small extent of a contraction -- the basis size, as m in the c, b, a contractions and as n
+    // in d and c -- covered EXACTLY by one tile, to the next multiple of 16: 100 + t = (16 t) x 64 with the four waves side
+    // by side along n, 200 + t = 64 x (16 t) with the waves stacked along m; t = 5 ... 16.  16-byte staging needs 16 t to be
+    // a multiple of 32: odd t takes the 8-byte form.
+    if constexpr (MODE == MODE_F64_VEC2) {
+        switch (cfg) {
+#define QS_FIT(T) case 100 + T: return launch_one<1, 4, T, 1, 16, MODE>(g, batch, s); case 200 + T: return launch_one<4, 1, 1, T, 16, MODE>(g, batch, s);
+            QS_FIT(6) QS_FIT(8) QS_FIT(10) QS_FIT(12) QS_FIT(14) QS_FIT(16)
+#undef QS_FIT
+            default: return QS_ERR_BAD_EXTENT;
+        }
+    } else {
+        switch (cfg) {
+#define QS_FIT(T) case 100 + T: return launch_one<1, 4, T, 1, 16, MODE>(g, batch, s); case 200 + T: return launch_one<4, 1, 1, T, 16, MODE>(g, batch, s);
+            QS_FIT(5) QS_FIT(6) QS_FIT(7) QS_FIT(8) QS_FIT(9) QS_FIT(10) QS_FIT(11) QS_FIT(12) QS_FIT(13) QS_FIT(14) QS_FIT(15) QS_FIT(16)
+#undef QS_FIT
+            default: return QS_ERR_BAD_EXTENT;
+        }
     }
 }
 
@@ -455,9 +480,35 @@ int gemm_f64(const double* A, const double* B, double* C, int64_t m, int64_t n, 
         };
         double cost = 0.0;
         cfg = pick_shape(cand, sizeof(cand) / sizeof(cand[0]), m, n, batch, &cost);
+        // Fitted shapes (see dispatch_f64): a basis size between 65 and 256 as m or as n.  Measured (same-box sweep with the
+        // shapes forced, profiles/r03_mid_size_shapes.txt): on their plain schedule they reach ~0.7 of the VALU-free kernel's
+        // rate -- they pay where everything is on 8-byte staging anyway (odd basis sizes) and the tile they save is large:
+        // l = 65 +14 %, 97 +12 %, 105 +11 %, 129 +4 %; with 16-byte staging available the other kernels win.
+        int fit_cfg = 0;
+        if (!vec) cost /= kScalarStagingRate;
+        if (g_tune.gemm_fit == 2 || (g_tune.gemm_fit == 1 && !vec)) {
+            const int tm = (int)cdiv(m, 16), tn = (int)cdiv(n, 16);
+            TileShape fit[2];
+            int nfit = 0;
+            // (from 13 tiles up the stages of a tile take more than half of a CU's LDS: one workgroup per CU)
+            auto weight = [](int t) { return t <= 9 ? 1.10 * kFitWeight : t <= 12 ? kFitWeight : 0.75 * kFitWeight; };
+            if (m <= 256 && tm >= 5) fit[nfit++] = TileShape{100 + tm, 16 * tm, 64, weight(tm)};
+            if (n <= 256 && tn >= 5) fit[nfit++] = TileShape{200 + tn, 64, 16 * tn, weight(tn)};
+            if (nfit) {
+                double fcost = 0.0;
+                const int fc = pick_shape(fit, nfit, m, n, batch, &fcost);
+                if (g_tune.gemm_fit == 2 || fcost < cost) { fit_cfg = fc; cost = fcost; }
+            }
+        }
         rc = gemm_fast_try(QS_F64, A, B, C, m, n, k, lda, ldb, ldc, batch, sa, sb, sc,
-                           accumulate, g.group_along_m, cost / kGeneralRelativeRate, stream);
+                           accumulate, g.group_along_m, g_tune.gemm_fit == 2 && fit_cfg ? 0.0 : cost / kGeneralRelativeRate, stream);
         if (rc != 1) return rc;
+        if (fit_cfg) {
+            // 16-byte staging only for an even tile count; an odd one takes the 8-byte form whatever the alignment
+            const bool odd = (fit_cfg % 100) & 1;
+            return (vec && !odd) ? dispatch_f64<MODE_F64_VEC2>(fit_cfg, g, batch, stream)
+                                 : dispatch_f64<MODE_F64_SCALAR>(fit_cfg, g, batch, stream);
+        }
     }
     return vec ? dispatch_f64<MODE_F64_VEC2>(cfg, g, batch, stream)
                : dispatch_f64<MODE_F64_SCALAR>(cfg, g, batch, stream);

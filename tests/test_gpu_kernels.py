@@ -540,6 +540,33 @@ def test_edge_form_product_vs_oracle(K, m, n, k, batch, cplx):
         K.tuning_set("gemm_fast_shape", 0)
 
 
+@pytest.mark.parametrize("m,n,k,batch", [(66, 4356, 66, 2), (130, 1000, 130, 1), (255, 300, 255, 1), (81, 81, 81, 5), (1000, 130, 130, 1),
+                                          (4356, 66, 66, 1), (500, 255, 77, 2), (97, 200, 97, 3), (144, 144, 144, 2)])
+def test_fitted_tile_shapes_vs_oracle(K, m, n, k, batch):
+    # the general kernel's FITTED shapes (round 3): the basis size covered by one tile, to the next multiple of 16 --
+    # (16 t) x 64 when it is the m extent (c, b, a contractions), 64 x (16 t) when it is n (d, c); odd t on 8-byte staging
+    rng = np.random.default_rng(m + n + k + batch)
+    A = rng.standard_normal((m, k))
+    B = rng.standard_normal((batch, k, n))
+    ref = np.matmul(A, B)
+    try:
+        K.tuning_set("gemm_fast", 0)
+        K.tuning_set("gemm_fit", 0)
+        general = host(K.matmul(dev(A), dev(B)))
+        assert "gemm_kernel<2, 2" in K.last_dispatch()
+        K.tuning_set("gemm_fit", 2)
+        got = host(K.matmul(dev(A), dev(B)))
+        ran = K.last_dispatch()
+        assert "gemm_kernel<1, 4, " in ran or "gemm_kernel<4, 1, 1, " in ran, ran
+        assert relerr(got, ref) <= 1e-13
+        assert np.array_equal(got, general)                # the same k-ordered sums: identical bits
+        out = dev(ref.copy())
+        K.matmul(dev(A), dev(B), out=out, accumulate=True)
+        assert relerr(host(out), 2 * ref) <= 1e-13
+    finally:
+        K.tuning_reset()
+
+
 def test_edge_form_keeps_non_finite_values_in_their_rows(K):
     # the K tail is removed with selects, not by multiplying with zero: a NaN/Inf in one row of A
     # (or one column of B) must not reach any other row (column) of the product

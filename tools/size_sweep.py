@@ -12,6 +12,9 @@ g = torch.Generator(device=dev).manual_seed(5)
 sizes = [int(v) for v in os.environ["QS_SWEEP_L"].split(",")] if os.environ.get("QS_SWEEP_L") else \
     [57, 60, 63, 64, 65, 66, 70, 72, 79, 80, 88, 95, 96, 97, 100, 104, 111, 112, 120, 127, 128, 129, 130, 136, 144, 150, 160, 176, 191,
      192, 193, 200, 208, 224, 240, 255, 256]
+for kv in os.environ.get("QS_SWEEP_TUNE", "").split(","):          # e.g. QS_SWEEP_TUNE=gemm_fit=2,gemm_fast=0
+    if "=" in kv:
+        K.tuning_set(kv.split("=")[0], int(kv.split("=")[1]))
 print("l dtype us TFLOP/s kernels")
 for cx in (False, True):
     for l in sizes:
@@ -43,3 +46,4 @@ for cx in (False, True):
         del u, out
         K.workspace.release()
         torch.cuda.empty_cache()
+K.tuning_reset()
