@@ -216,6 +216,7 @@ int qs_tuning_set(const char* key, int64_t value) {
     if (!strcmp(key, "gemm_stream")) { g_tune.gemm_stream = (int)value; return QS_OK; }
     if (!strcmp(key, "slab_pair")) { g_tune.slab_pair = (int)value; return QS_OK; }
     if (!strcmp(key, "gemm_fast_persist")) { g_tune.gemm_fast_persist = (int)value; return QS_OK; }
+    if (!strcmp(key, "sandwich_tail")) { g_tune.sandwich_tail = (int)value; return QS_OK; }
     if (!strcmp(key, "gemm_fast_shape")) { g_tune.gemm_fast_shape = (int)value; return QS_OK; }
     if (!strcmp(key, "gemm_pick")) { g_tune.gemm_pick = (int)value; return QS_OK; }
     if (!strcmp(key, "small4")) { g_tune.small4 = (int)value; return QS_OK; }
@@ -340,10 +341,12 @@ static int transform_two_body_impl(int in_dtype, int dtype, const void* u, const
             // T2 transposed, (r, s, a, b): the second pass then fetches slabs like the first (64-byte runs, the four
             // waves of a workgroup on the same lines) instead of columns (32-byte runs), and the first one stores the
             // way the second does.  Same-box sweep (profiles/r02_small_basis_sweep.txt): 4-10 % faster for
-            // ceil(l/4) in {10, 13, 14, 16}, faster than the second pass alone for 11, slower for 9 and 12; 15 has
+            // ceil(l/4) in {10, 13, 14, 16}, faster than the second pass alone for 11, slower for 9 and l = 48 (45 ... 47:
+            // faster since round 3, gpurun_out r03y tail_ab*); 15 has
             // slab passes only (the balanced kernel's instantiation for 16).
             const bool want_t2 = second_tr && (!second_nat || (g_tune.sandwich_t2 >= 0 ? g_tune.sandwich_t2 != 0
-                                                                                         : (n4 == 10 || n4 == 11 || n4 >= 13)));
+                                                                                         : (n4 == 10 || n4 == 11 || n4 >= 13 ||
+                                                                                            (n4 == 12 && L % 4 != 0))));
             bool t2_transposed = false;
             if (g_tune.sandwich != 3 && g_tune.sandwich != 6) {
                 if (want_t2)

@@ -156,6 +156,7 @@ struct Tuning {
     int gemm_fast = 1;           // 0 general kernel only, 1 automatic, 2 exact form only, 3 edge form wherever legal
     int gemm_fast_persist = 1;   // 0 one workgroup per tile, 1 automatic, 2 always persistent, >= 3 tiles per workgroup
     int gemm_pick = 1;           // tile shape of the general kernel: 1 by rounds over the resident workgroups x tile work, 0 by padded area
+    int sandwich_tail = 1;       // balanced small-basis kernel: the quads of a partly filled last round split over all workgroups
     int gemm_fast_shape = 0;     // forces edge-form shape 1..N (0 = by padded-work cost)
     int gemm_fit = 1;            // fitted tile shapes of the general kernel (the basis size covered by one tile, to the next multiple of
                                  // 16): 1 by estimated time, 2 wherever they exist, 0 off

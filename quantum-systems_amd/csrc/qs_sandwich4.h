@@ -17,6 +17,8 @@ struct S4Args {
     int64_t out_item, out_row, out_col;    // element strides of Out_t[p][j]
     int L, M;
     unsigned nitems, nquads;
+    unsigned tail_first, tail_parts;   // balanced form only (else 0, 0): item quads from tail_first on -- the partly filled last
+                                       // round -- are split into tail_parts column-group parts, one workgroup each
     int mode;      // bit 0: the four waves take four ADJACENT item quads and the same chunk (else: one quad, four chunks);
                    // bit 1: with bit 0, a workgroup barrier per step keeps the four waves' fetches together in L1
 };
@@ -25,5 +27,8 @@ struct S4Args {
 // {10, 12, 14, 16}, each for 4 (n4 - 2) < L, M <= 4 n4.
 // QS_OK / error after launching, 1 = no such instantiation; with `dry_run` nothing is launched (QS_OK = would launch).
 int sandwich4b_launch(const S4Args& g, int n4, hipStream_t stream, int dry_run);
+// Does the balanced form split the last round of `nquads` item quads (M columns) over all workgroups?  (One task per
+// workgroup must cover its quads; g_tune.sandwich_tail.)
+bool sandwich4b_tail_applies(unsigned nquads, int M);
 
 }  // namespace qs

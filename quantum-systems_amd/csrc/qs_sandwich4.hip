@@ -561,7 +561,8 @@ int sandwich4_try(int dtype, const void* in, void* out, const void* R, int64_t r
     int n4k = n4;
     bool v2 = in_col == 1 && (g_tune.sandwich_v2 > 0 ||
                               (g_tune.sandwich_v2 < 0 && (n4 == 10 || n4 == 12 || n4 == 14 || n4 == 16) &&
-                               !(L % 4 == 0 && (n4 == 10 || n4 == 14))));
+                               (!(L % 4 == 0 && (n4 == 10 || n4 == 14)) ||
+                                sandwich4b_tail_applies((unsigned)cdiv(nitems, 4), (int)M))));    // (l = 56: its last round is split there)
     if (in_col == 1 && (n4 & 1) && n4 >= 9 && (g_tune.sandwich_v2 == 2 || (g_tune.sandwich_v2 < 0 && (n4 == 11 || n4 == 15)))) {
         v2 = true;
         n4k = n4 + 1;
@@ -573,11 +574,12 @@ int sandwich4_try(int dtype, const void* in, void* out, const void* R, int64_t r
     //   * below ceil(l/4) = 9 the transform is launch-bound either way;
     //   * slabs in, slabs out (the (d, c) pass with T2 in its natural layout) lose for ceil(l/4) = 11, and for 12 unless
     //     the balanced form runs;
-    //   * slabs in, interleaved items out (either pass when T2 is stored transposed) lose for ceil(l/4) = 12.
+    //   * slabs in, interleaved items out (either pass when T2 is stored transposed) lose for l = 48 (round 3, with the
+    //     balanced kernel's tail: l = 45 50.6 -> 44.2 us, 46 55.5 -> 54.2, 47 58.6 -> 57.5, 48 60.5 -> 63.3).
     if (g_tune.sandwich < 4) {
         if (n4 < 9 || (n4 == 15 && !v2)) return 1;
         if (in_item != 1 && out_item != 1 && (n4 == 11 || (n4 == 12 && !v2))) return 1;
-        if (in_item != 1 && out_item == 1 && n4 == 12) return 1;
+        if (in_item != 1 && out_item == 1 && n4 == 12 && L % 4 == 0) return 1;     // (45 ... 47: see qs_api.hip)
     }
     // every byte offset inside an item quad stays below 2^31
     const int64_t in_span = (3 * in_item + (4 * n4) * (in_row > in_col ? in_row : in_col) * 2) * 8;
@@ -592,6 +594,7 @@ int sandwich4_try(int dtype, const void* in, void* out, const void* R, int64_t r
     g.L = (int)L; g.M = (int)M;
     g.nitems = (unsigned)nitems;
     g.nquads = (unsigned)cdiv(nitems, 4);
+    g.tail_first = g.nquads; g.tail_parts = 0;
     // items 8 bytes apart (the (b, a) pass): four adjacent quads per workgroup make whole lines; contiguous items
     // (the (d, c) pass): a workgroup per quad keeps its four fetch streams on the same lines
     g.mode = g_tune.sandwich_mode >= 0 ? g_tune.sandwich_mode : (in_item == 1 ? 3 : 0);

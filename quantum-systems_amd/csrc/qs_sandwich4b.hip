@@ -113,8 +113,9 @@ __global__ __launch_bounds__(256, 1) void sandwich4b_kernel(const S4Args g) {
     // ---- work units = item quads.  Every XCD takes a contiguous range and neighbouring workgroups of an XCD take
     // neighbouring quads.
     const unsigned n_xcd = 8, xcd = blockIdx.x % n_xcd, slot = blockIdx.x / n_xcd, slots = gridDim.x / n_xcd;
-    const unsigned per = (g.nquads + n_xcd - 1) / n_xcd;
-    const unsigned u_end = (xcd + 1) * per < g.nquads ? (xcd + 1) * per : g.nquads;
+    const unsigned nmain = g.tail_parts ? g.tail_first : g.nquads;      // (with a tail: a whole number of rounds of the grid)
+    const unsigned per = (nmain + n_xcd - 1) / n_xcd;
+    const unsigned u_end = (xcd + 1) * per < nmain ? (xcd + 1) * per : nmain;
     unsigned iq = xcd * per + slot;
     if (iq >= u_end) return;                           // (whole workgroup: before any barrier)
 
@@ -474,7 +475,104 @@ __global__ __launch_bounds__(256, 1) void sandwich4b_kernel(const S4Args g) {
 #pragma unroll
         for (int c = 0; c < 2; ++c) { rd_in[0][c] = rd_nx[0][c]; rd_in[1][c] = rd_nx[1][c]; }
     }
+    // ---- The TAIL: the item quads of a partly filled last round (56 orbitals: 784 quads = 3 rounds of 256 workgroups
+    // + 16 quads, for which every workgroup used to wait a fourth round, 83 -> 113 us against l = 55) are split by column
+    // groups over ALL workgroups -- task = (quad, part): the four waves take the groups 4 part ... 4 part + 3, one each,
+    // both products.  Nothing of the main loop's machinery is needed: the whole item quad goes into LDS at once (every
+    // wave a quarter of the fragment pairs, in MFMA lane order through the same swizzle as the transit buffer: over the
+    // fragments of R -- each wave reads its group's first -- and over the transit sets; the fragments of Lm stay), the A
+    // operands of the first product come from there, those of the second from the table.  Per-element sums are the same
+    // k-ordered chains.
+    if (g.tail_parts) {                                           // (kernel-uniform)
+        constexpr int RS = N4 / 4;                                // sets that fit over the fragments of R (N4 N4 16 >= RS SET)
+        const unsigned task = blockIdx.x;
+        const unsigned tq = g.tail_first + task / g.tail_parts;   // (workgroup-uniform)
+        if (tq < g.nquads) {
+            const int jg = 4 * (int)(task % g.tail_parts) + wave;
+            const bool has_group = 4 * jg < M;                    // (wave-uniform; such a wave still fetches and takes the barriers)
+            const int jgc = has_group ? jg : 0;
+            __syncthreads();                                      // everybody is through with the transit buffer
+            double bt[N4];
+            unroll_b<0, N4>([&](auto KS) __attribute__((always_inline)) {
+                bt[decltype(KS)::value] = rtab[(decltype(KS)::value * N4 + jgc) * 16 + e_lane];
+            });
+            auto set_of = [&](int r) __attribute__((always_inline)) {
+                return lds + (r < RS ? r * SET : 2 * N4 * N4 * 16 + (r - RS) * SET);
+            };
+            unsigned v_t[PW][3], w_t[PW][2][2], rd_t[2][2];
+            in_offsets(tq, true, 0u, v_t, w_t, rd_t);             // (v_t: lane offsets; the positions are this block's own)
+            auto rs_t = rsrc(g.in - 1, tq, g.in_item);
+            double tl[N4][PW][2];
+            unroll_b<0, N4>([&](auto R_) __attribute__((always_inline)) {
+                unroll_b<0, PW>([&](auto I_) __attribute__((always_inline)) {
+                    load_into(rs_t, v_t, R_, I_, tl[decltype(R_)::value][decltype(I_)::value]);
+                });
+            });
+            const unsigned p0 = f_par * 64 + slot_pos(f_row, f_item, f_k0, f_par);
+            const unsigned p1 = f_par * 64 + slot_pos(f_row, f_item, f_k0 + 1, f_par);
+            const int k_last = 8 * (NP - 1) + 4 * f_par + f_k0;
+            const bool shift = k_last < L && !(k_last + 1 < L);   // the last k of an odd L: fetched 8 bytes early (in_offsets)
+            lds_barrier();                                        // the fragments of R are in registers: their table may go
+            unroll_b<0, N4>([&](auto R_) __attribute__((always_inline)) {
+                constexpr int r = decltype(R_)::value;
+                double* const set = set_of(r);
+                unroll_b<0, PW>([&](auto I_) __attribute__((always_inline)) {
+                    constexpr int i = decltype(I_)::value;
+                    const int m = wave + 4 * i;                   // (wave-uniform)
+                    if (m < NP) {
+                        const bool sh = m == NP - 1 && shift;
+                        set[m * 128 + p0] = sh ? tl[r][i][1] : tl[r][i][0];
+                        set[m * 128 + p1] = sh ? 0.0 : tl[r][i][1];
+                    }
+                });
+            });
+            __syncthreads();
+            if (has_group) {
+                // Y[ka] = In[ka] . R[:, group]: two chains at a time (a single one waits 4 cycles per link)
+                double Yt[N4];
+                unroll_b<0, N4 / 2>([&](auto H_) __attribute__((always_inline)) {
+                    constexpr int ka = 2 * decltype(H_)::value;
+                    const double* const s0 = set_of(ka);
+                    const double* const s1 = set_of(ka + 1);
+                    unroll_b<0, N4>([&](auto KS) __attribute__((always_inline)) {
+                        constexpr int ks = decltype(KS)::value;
+                        const unsigned rd = (ks & 1) ? rd_odd : rd_even;
+                        Yt[ka] = mfma4b(s0[ks * 64 + rd], bt[ks], ks == 0 ? 0.0 : Yt[ka]);
+                        Yt[ka + 1] = mfma4b(s1[ks * 64 + rd], bt[ks], ks == 0 ? 0.0 : Yt[ka + 1]);
+                    });
+                });
+                // Out[pg] = sum_ka Lm[pg][ka] . Y[ka], stored as it is finished
+                unsigned v_o[3];
+                out_offsets(tq, v_o);
+                const auto rs_o = rsrc(g.out, tq, g.out_item);
+                const bool col_ok = 4 * jg + x < M;
+                unroll_b<0, N4 / 2>([&](auto H_) __attribute__((always_inline)) {
+                    constexpr int pg = 2 * decltype(H_)::value;
+                    double o0 = 0.0, o1 = 0.0;
+                    unroll_b<0, N4>([&](auto KA) __attribute__((always_inline)) {
+                        constexpr int ka = decltype(KA)::value;
+                        o0 = mfma4b(ltab[(pg * N4 + ka) * 16 + e_lane], Yt[ka], ka == 0 ? 0.0 : o0);
+                        o1 = mfma4b(ltab[((pg + 1) * N4 + ka) * 16 + e_lane], Yt[ka], ka == 0 ? 0.0 : o1);
+                    });
+                    const unsigned s_col = (unsigned)jg * jg_step;
+                    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2b, o0), rs_o,
+                        (int)(col_ok ? v_o[pg == N4 - 2 ? 1 : 0] : kParkedB), (int)(pg * pg_step + s_col), 0);
+                    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2b, o1), rs_o,
+                        (int)(col_ok ? v_o[pg + 1 == N4 - 1 ? 2 : 0] : kParkedB), (int)((pg + 1) * pg_step + s_col), 0);
+                });
+            }
+        }
+    }
     QS_S4B_TRACE_DONE
+}
+
+bool sandwich4b_tail_applies(unsigned nquads, int M) {
+    if (!g_tune.sandwich_tail) return false;
+    const int n_cu = device_cu_count();
+    const unsigned wgs = (unsigned)(n_cu - n_cu % 8);
+    if (wgs < 8 || nquads <= wgs) return false;
+    const unsigned ntail = nquads % wgs, parts = (unsigned)((cdiv(M, 4) + 3) / 4);
+    return ntail && ntail * parts <= wgs;
 }
 
 template <int N4>
@@ -485,12 +583,23 @@ static int launch_sandwich4b(const S4Args& g, hipStream_t stream, int dry_run) {
     if (wgs < 8) wgs = 8;
     const int64_t need = ((int64_t)g.nquads + 7) / 8 * 8;
     if (wgs > need) wgs = need;                          // short item lists: no idle workgroups
-    const size_t lds = sizeof(double) * (2 * N4 * N4 * 16 + 8 * N4 * 64 + ((N4 % 4) ? 2 * N4 * 64 : 0));
+    size_t lds = sizeof(double) * (2 * N4 * N4 * 16 + 8 * N4 * 64 + ((N4 % 4) ? 2 * N4 * 64 : 0));
+    // A last round that is only partly filled: its quads split over all workgroups (the kernel's tail), when one task
+    // per workgroup covers them.  (The whole-quad staging of the tail takes N4 - N4 / 4 sets behind the tables.)
+    S4Args gt = g;
+    if (sandwich4b_tail_applies(g.nquads, g.M)) {
+        const size_t lds_tail = sizeof(double) * (2 * N4 * N4 * 16 + (N4 - N4 / 4) * N4 * 64);
+        if (lds_tail <= 160 * 1024) {
+            gt.tail_first = g.nquads / (unsigned)wgs * (unsigned)wgs;
+            gt.tail_parts = (unsigned)((cdiv(g.M, 4) + 3) / 4);
+            if (lds_tail > lds) lds = lds_tail;
+        }
+    }
     static PerDeviceLds lds_opt_in;
     if (int rc = opt_in_dynamic_lds((const void*)sandwich4b_kernel<N4>, lds, lds_opt_in, "hipFuncSetAttribute(sandwich4b)"))
         return rc;
-    hipLaunchKernelGGL(sandwich4b_kernel<N4>, dim3((unsigned)wgs), dim3(256), lds, stream, g);
-    note_dispatch("qs::sandwich4b_kernel<%d>", N4);
+    hipLaunchKernelGGL(sandwich4b_kernel<N4>, dim3((unsigned)wgs), dim3(256), lds, stream, gt);
+    note_dispatch(gt.tail_parts ? "qs::sandwich4b_kernel<%d>+tail" : "qs::sandwich4b_kernel<%d>", N4);
     return launch_status("sandwich4b launch");
 }
 

@@ -732,7 +732,7 @@ def _sandwich_launches(dispatch, n4):
     for item in dispatch.split(";"):
         m = re.fullmatch(rf"qs::sandwich4_kernel<{n4}>(?: x(\d+))?", item)
         if not m:
-            m = re.fullmatch(rf"qs::sandwich4b_kernel<({n4}|{n4 + (n4 & 1)})>(?: x(\d+))?", item)
+            m = re.fullmatch(rf"qs::sandwich4b_kernel<({n4}|{n4 + (n4 & 1)})>(?:\+tail)?(?: x(\d+))?", item)
             if not m:
                 return 0
             total += int(m.group(2) or 1)
@@ -741,8 +741,8 @@ def _sandwich_launches(dispatch, n4):
     return total
 
 
-@pytest.mark.parametrize("L,M", [(32, 32), (33, 33), (36, 34), (40, 40), (41, 44), (47, 48), (50, 49), (53, 55),
-                                 (55, 55), (55, 53), (56, 56), (58, 60), (61, 64), (64, 64)])
+@pytest.mark.parametrize("L,M", [(32, 32), (33, 33), (36, 34), (40, 40), (41, 44), (46, 46), (47, 48), (48, 48), (50, 49),
+                                 (53, 55), (55, 55), (55, 53), (56, 56), (57, 57), (58, 60), (61, 64), (64, 64)])
 def test_sandwich_passes_bit_identical_to_the_16_wide_path(K, L, M):
     # (d, c) per slab and (b, a) per column as Out = Lm . In . R on v_mfma_f64_4x4x4_4b_f64: four items per
     # instruction, extents padded to 4 instead of 16, Y chained through the accumulators.  The sums are the same
@@ -777,6 +777,26 @@ def test_sandwich_passes_bit_identical_to_the_16_wide_path(K, L, M):
         # (ceil(l/4) = 15 has its second pass only on slabs through the balanced kernel: without either, one fused pass)
         if knobs.get("sandwich") == 4 and not (-(-L // 4) == 15 and 0 in (knobs.get("sandwich_t2"), knobs.get("sandwich_v2"))):
             assert _sandwich_launches(disp, -(-L // 4)) == 2, disp
+
+
+@pytest.mark.parametrize("l", [46, 47, 48, 56, 57])
+def test_sandwich_tail_splits_a_partly_filled_last_round(K, l):
+    # 56 orbitals: 784 item quads = 3 rounds of the 256 workgroups + 16 quads; those are split by column groups over all
+    # workgroups inside the launch (qs_sandwich4b.hip, "+tail" in the dispatch record) -- same bits with and without
+    if torch.cuda.get_device_properties(0).multi_processor_count != 256:
+        pytest.skip("the sizes are chosen for 256 CUs")
+    rng = np.random.default_rng(l)
+    du = dev(rng.standard_normal((l,) * 4))
+    dC = dev(np.linalg.qr(rng.standard_normal((l, l)))[0])
+    with K.tuning(sandwich_tail=0):
+        plain = K.transform_two_body(du, dC)
+        assert "sandwich4" in K.last_dispatch() and "+tail" not in K.last_dispatch()
+    got = K.transform_two_body(du, dC)
+    n4 = -(-l // 4)      # (ceil(l/4) = 12 runs its second pass on columns, in the first kernel)
+    assert K.last_dispatch().startswith(f"qs::sandwich4b_kernel<{n4 + (n4 & 1)}>+tail")
+    assert torch.equal(got, plain)
+    with K.tuning(sandwich=0):
+        assert torch.equal(K.transform_two_body(du, dC), plain)
 
 
 def test_sandwich_is_the_automatic_choice_for_config_2(K):
