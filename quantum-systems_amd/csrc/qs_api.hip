@@ -302,11 +302,11 @@ static int transform_two_body_impl(int in_dtype, int dtype, const void* u, const
     }
 
     // complex128 up to 56 orbitals: the same two passes with two items per matrix instruction (qs_pair4c.hip).  Automatic
-    // where it measured faster than the four 16-wide passes (same-box sweep, profiles/r03_pair4c.txt): 25 ... 47 orbitals,
-    // 1.02-1.25x; from 48 up the accumulators and B operands of its eight waves crowd out the prefetch of the next item pair
-    // and it falls behind (l = 55: 0.81x).  g_tune.pair4c == 2: wherever it exists.
+    // where it measured faster than the four 16-wide passes (same-box sweeps, profiles/r03_pair4c.txt): 25 ... 48 orbitals
+    // except 32 itself, 1.08-1.45x with one wave per column group (section 4); from 49 up a wave is left with 128 registers
+    // (fourteen waves: four on a SIMD), spills, and falls behind (l = 55: 0.90x).  g_tune.pair4c == 2: wherever it exists.
     if (in_dtype == dtype && dtype == QS_C128 && g_tune.pair4c && L <= 56 && M <= 56 && n4s == cdiv(M, 4) &&
-        (g_tune.pair4c == 2 || (n4s >= 7 && (n4s <= 11 || (n4s == 12 && L <= 47 && M <= 47))))) {
+        (g_tune.pair4c == 2 || (n4s >= 7 && n4s <= 12 && !(L == 32 && M == 32)))) {
         const int64_t MM = M * M;
         int rc1 = pair4c_try(dtype, u, WA, C, M, 1, C, 1, M, L * L, L, M, L * L, L, 1, MM, M, 1, 0, s);
         if (rc1 == QS_OK)

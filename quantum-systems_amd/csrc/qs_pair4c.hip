@@ -92,11 +92,22 @@ struct GeoC {
     static constexpr int lds_doubles = 2 * plane_pitch + 2 * table;
 };
 
-// Work split of a workgroup (measured, profiles/r03_pair4c.txt): eight waves -- two per SIMD, which cover each other's LDS
-// latency and the gaps of the dependent MFMAs of a row quad of Y -- with two column groups each.  Four waves with four
-// groups each (one per SIMD, 512 registers: room for everything up to 48 orbitals) measured 10-20 % SLOWER at every size.
-constexpr int pair_threads(int) { return 512; }
-constexpr int pair_groups(int) { return 2; }
+// Work split of a workgroup (measured, profiles/r03_pair4c.txt).  Up to 24 orbitals: eight waves -- two per SIMD, which
+// cover each other's LDS latency and the gaps of the dependent MFMAs of a row quad of Y -- with two column groups each.
+// From 25 orbitals: ONE WAVE PER COLUMN GROUP (N4 waves, 64 N4 threads).  With two groups per wave the busy waves of a
+// basis of 33 ... 48 orbitals were 4.5 ... 6 on four SIMDs (loads 2, 1, 1, 1 to 2, 2, 1, 1: 56-75 % of the matrix pipes);
+// with one group each they are 9 ... 12 (3, 2, 2, 2 to 3, 3, 3, 3), the B operands and accumulators of a wave halve, and
+// three waves per SIMD cover each other's waits: +9 % at 25 ... 30 orbitals, +13-18 % at 33 ... 48 (section 4).  The A
+// fragments are then read once per MFMA pair instead of once per two: half of the LDS read rate (256 B per clock and CU).
+// Four waves with four groups each (one per SIMD, 512 registers) measured 10-20 % SLOWER at every size.
+#ifndef QS_PAIR4C_PREFETCH_TO
+#define QS_PAIR4C_PREFETCH_TO 10
+#endif
+#ifndef QS_PAIR4C_WIDE_FROM
+#define QS_PAIR4C_WIDE_FROM 7
+#endif
+constexpr int pair_threads(int n4) { return n4 >= QS_PAIR4C_WIDE_FROM ? 64 * n4 : 512; }
+constexpr int pair_groups(int n4) { return n4 >= QS_PAIR4C_WIDE_FROM ? 1 : 2; }
 
 }  // namespace
 
@@ -211,7 +222,7 @@ __global__ __launch_bounds__(pair_threads(N4)) void pair4c_kernel(const Pair4Arg
     // The next pair travels during this one's products (its elements wait in registers) -- up to 40 orbitals; above, the B
     // operands and the accumulators leave no room for them in the 256 registers of a wave, and the loads of a pair are
     // issued when its turn comes (their latency is then in the open)
-    constexpr bool PREFETCH = N4 <= 10;
+    constexpr bool PREFETCH = N4 <= QS_PAIR4C_PREFETCH_TO;
     for (bool first = true; unit < u_end; unit += slots, first = false) {
         if (!PREFETCH && !first) stage_load(unit);
         __syncthreads();                                    // the previous pair's readers are done

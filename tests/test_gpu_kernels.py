@@ -174,13 +174,14 @@ def test_complex_fused_kernel_is_bit_identical_to_the_16_wide_path(K):
     # qs_pair4c.hip: both fused passes of a COMPLEX128 basis of up to 56 orbitals, two items per matrix instruction (blocks =
     # (item, re | im)); the same chains of fused multiply-adds as the four 16-wide passes, element for element.
     rng = np.random.default_rng(77)
-    shapes = [(25, 25), (28, 27), (29, 32), (33, 33), (36, 34), (37, 40), (41, 44), (47, 45), (48, 48), (49, 52), (55, 55), (56, 53)]
+    shapes = [(25, 25), (28, 27), (29, 32), (32, 32), (33, 33), (36, 34), (37, 40), (41, 44), (47, 45), (48, 48), (49, 52), (55, 55),
+              (56, 53)]
     small = [(3, 3), (8, 6), (13, 16), (21, 24)]            # (qs_small4.hip is the automatic choice there)
     for (L, M) in shapes + small:
         u = dev(rng.standard_normal((L,) * 4) + 1j * rng.standard_normal((L,) * 4))
         C = dev((rng.standard_normal((L, M)) + 1j * rng.standard_normal((L, M))) / np.sqrt(L))
         Ct = dev((rng.standard_normal((M, L)) + 1j * rng.standard_normal((M, L))) / np.sqrt(L))
-        auto = 25 <= max(L, M) <= 47 and min(L, M) > 24
+        auto = 25 <= max(L, M) <= 48 and min(L, M) > 24 and (L, M) != (32, 32)
         K.tuning_set("pair4c", 2)
         K.tuning_set("small4", 0)
         try:
