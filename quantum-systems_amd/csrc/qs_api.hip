@@ -346,7 +346,8 @@ static int transform_two_body_impl(int in_dtype, int dtype, const void* u, const
             // slab passes only (the balanced kernel's instantiation for 16).
             const bool want_t2 = second_tr && (!second_nat || (g_tune.sandwich_t2 >= 0 ? g_tune.sandwich_t2 != 0
                                                                                          : (n4 == 10 || n4 == 11 || n4 >= 13 ||
-                                                                                            (n4 == 12 && L % 4 != 0))));
+                                                                                            (n4 == 12 && L % 4 != 0) ||
+                                                                                            (n4 == 9 && L == 36 && M == 36 && g_tune.sandwich_tail))));
             bool t2_transposed = false;
             if (g_tune.sandwich != 3 && g_tune.sandwich != 6) {
                 if (want_t2)

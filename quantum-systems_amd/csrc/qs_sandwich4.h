@@ -27,8 +27,8 @@ struct S4Args {
 // {10, 12, 14, 16}, each for 4 (n4 - 2) < L, M <= 4 n4.
 // QS_OK / error after launching, 1 = no such instantiation; with `dry_run` nothing is launched (QS_OK = would launch).
 int sandwich4b_launch(const S4Args& g, int n4, hipStream_t stream, int dry_run);
-// Does the balanced form split the last round of `nquads` item quads (M columns) over all workgroups?  (One task per
-// workgroup must cover its quads; g_tune.sandwich_tail.)
-bool sandwich4b_tail_applies(unsigned nquads, int M);
+// The item quads of the last round of `nquads` (M columns) that the balanced form splits over all workgroups; 0 = it does
+// not (no partly filled last round, or more tasks than workgroups; g_tune.sandwich_tail).
+unsigned sandwich4b_tail_quads(unsigned nquads, int M);
 
 }  // namespace qs

@@ -559,11 +559,15 @@ int sandwich4_try(int dtype, const void* in, void* out, const void* R, int64_t r
     // spills here, runs on the one for 16 (l = 57 ... 60: 150-185 -> 130-140 us), 11 on the one for 12 (44 -> 38 us);
     // 9 and 13 measured slower that way (g_tune.sandwich_v2 == 2: every odd one on the next even one).
     int n4k = n4;
+    const unsigned tail_quads = sandwich4b_tail_quads((unsigned)cdiv(nitems, 4), (int)M);
     bool v2 = in_col == 1 && (g_tune.sandwich_v2 > 0 ||
                               (g_tune.sandwich_v2 < 0 && (n4 == 10 || n4 == 12 || n4 == 14 || n4 == 16) &&
                                (!(L % 4 == 0 && (n4 == 10 || n4 == 14)) ||
-                                sandwich4b_tail_applies((unsigned)cdiv(nitems, 4), (int)M))));    // (l = 56: its last round is split there)
-    if (in_col == 1 && (n4 & 1) && n4 >= 9 && (g_tune.sandwich_v2 == 2 || (g_tune.sandwich_v2 < 0 && (n4 == 11 || n4 == 15)))) {
+                                tail_quads)));                                           // (l = 56: its last round is split there)
+    // (9: only for the sake of the tail -- 35 and 36 orbitals are 1.2 and 1.27 rounds of item quads: l = 35 31.1 -> 28.6 us with the
+    // first pass there, l = 36 37.0 -> 32.6 with both; 33 and 34, 17 and 33 quads over, are not worth the wider instantiation)
+    if (in_col == 1 && (n4 & 1) && n4 >= 9 && (g_tune.sandwich_v2 == 2 || (g_tune.sandwich_v2 < 0 && (n4 == 11 || n4 == 15 ||
+                                                                                                       (n4 == 9 && tail_quads >= 48))))) {
         v2 = true;
         n4k = n4 + 1;
     }

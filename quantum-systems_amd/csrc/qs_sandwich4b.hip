@@ -566,13 +566,13 @@ __global__ __launch_bounds__(256, 1) void sandwich4b_kernel(const S4Args g) {
     QS_S4B_TRACE_DONE
 }
 
-bool sandwich4b_tail_applies(unsigned nquads, int M) {
-    if (!g_tune.sandwich_tail) return false;
+unsigned sandwich4b_tail_quads(unsigned nquads, int M) {
+    if (!g_tune.sandwich_tail) return 0;
     const int n_cu = device_cu_count();
     const unsigned wgs = (unsigned)(n_cu - n_cu % 8);
-    if (wgs < 8 || nquads <= wgs) return false;
+    if (wgs < 8 || nquads <= wgs) return 0;
     const unsigned ntail = nquads % wgs, parts = (unsigned)((cdiv(M, 4) + 3) / 4);
-    return ntail && ntail * parts <= wgs;
+    return ntail * parts <= wgs ? ntail : 0;
 }
 
 template <int N4>
@@ -587,7 +587,7 @@ static int launch_sandwich4b(const S4Args& g, hipStream_t stream, int dry_run) {
     // A last round that is only partly filled: its quads split over all workgroups (the kernel's tail), when one task
     // per workgroup covers them.  (The whole-quad staging of the tail takes N4 - N4 / 4 sets behind the tables.)
     S4Args gt = g;
-    if (sandwich4b_tail_applies(g.nquads, g.M)) {
+    if (sandwich4b_tail_quads(g.nquads, g.M)) {
         const size_t lds_tail = sizeof(double) * (2 * N4 * N4 * 16 + (N4 - N4 / 4) * N4 * 64);
         if (lds_tail <= 160 * 1024) {
             gt.tail_first = g.nquads / (unsigned)wgs * (unsigned)wgs;
