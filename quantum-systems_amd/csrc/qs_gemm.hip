@@ -442,6 +442,9 @@ static int dispatch_f64(int cfg, const GemmArgs& g, int64_t batch, hipStream_t s
     // in d and c -- covered EXACTLY by one tile, to the next multiple of 16: 100 + t = (16 t) x 64 with the four waves side
     // by side along n, 200 + t = 64 x (16 t) with the waves stacked along m; t = 5 ... 16.  16-byte staging needs 16 t to be
     // a multiple of 32: odd t takes the 8-byte form.
+#ifdef QS_DEV_FEW_SHAPES      // development / sanitizer builds of the HOST side: two dozen instantiations less to compile
+    return QS_ERR_BAD_EXTENT;
+#else
     if constexpr (MODE == MODE_F64_VEC2) {
         switch (cfg) {
 #define QS_FIT(T) case 100 + T: return launch_one<1, 4, T, 1, 16, MODE>(g, batch, s); case 200 + T: return launch_one<4, 1, 1, T, 16, MODE>(g, batch, s);
@@ -457,6 +460,7 @@ static int dispatch_f64(int cfg, const GemmArgs& g, int64_t batch, hipStream_t s
             default: return QS_ERR_BAD_EXTENT;
         }
     }
+#endif
 }
 
 int gemm_f64(const double* A, const double* B, double* C, int64_t m, int64_t n, int64_t k,
