@@ -288,12 +288,12 @@ static int transform_two_body_impl(int in_dtype, int dtype, const void* u, const
     // up to 32 orbitals, both dtypes: two launches of the LDS-staged kernel (what is left below ~33 orbitals is launches, not
     // work: the 16-wide kernels need three to five); T2 (L, L, M, M) in WA
     // (same-box sweep with the launches of a transform captured in one graph, profiles/r03_small4.txt: 1.8-2.9x up to 15
-    // orbitals for both dtypes, 1.1-1.4x for complex128 up to 24; fp64 from 17 and complex128 from 25 orbitals level
-    // with the 16-wide kernels or behind them -- what the kernel waits for there is the one round trip of its loads and the
+    // orbitals for both dtypes, 1.1-1.4x for complex128 up to 24, 1.04x for fp64 at 17 ... 20 with eight waves; fp64 from 21
+    // and complex128 from 25 orbitals level with the 16-wide kernels or behind them -- what the kernel waits for there is the one round trip of its loads and the
     // drain of its stores, with one workgroup per CU and nothing to overlap them with.  g_tune.small4 == 2: wherever it exists)
     const int64_t n4s = cdiv(L, 4);
     if (in_dtype == dtype && g_tune.small4 && L <= 32 && M <= 32 && n4s == cdiv(M, 4) &&
-        (g_tune.small4 == 2 || n4s <= (dtype == QS_C128 ? 6 : 4))) {
+        (g_tune.small4 == 2 || n4s <= (dtype == QS_C128 ? 6 : 5))) {
         const int64_t MM = M * M;
         int rc1 = small4_try(dtype, u, WA, C, M, 1, C, 1, M, L * L, L, M, L * L, L, 1, MM, M, 1, 0, s);
         if (rc1 == QS_OK)

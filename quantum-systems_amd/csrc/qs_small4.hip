@@ -86,14 +86,20 @@ struct Geo {
 // How the column groups of a quad are shared out (measured, profiles/r03_small4.txt): a wave takes NJ groups at a time (an
 // A fragment read from LDS feeds NJ MFMAs: with NJ = 1 four fp64 waves would ask LDS for 128 bytes per clock, its
 // peak), NW waves per workgroup.  Up to 16 orbitals one group per wave keeps all four waves busy; complex128 reads an A
-// fragment per two MFMAs, so eight waves with one group each halve the longest chain of a workgroup.
+// fragment per two MFMAs, so eight waves with one group each halve the longest chain of a workgroup.  (LDS reads 256
+// bytes per clock for 8-byte accesses on gfx950, not 128: the same eight-wave split for fp64 above 16 orbitals measured
+// 3-9 % faster, l = 17 10.5 -> 9.7 us, 20 11.1 -> 10.2, 28 20.1 -> 18.3, and is the default since; QS_SMALL4_WIDE_F64=0
+// builds the four-wave form.)
+#ifndef QS_SMALL4_WIDE_F64
+#define QS_SMALL4_WIDE_F64 1
+#endif
 template <bool CX, int N4>
 struct Split {
-    static constexpr int NJ = (CX || N4 <= 4) ? 1 : 2;
-    static constexpr int NW = (CX && N4 > 4) ? 8 : 4;
+    static constexpr int NJ = (CX || QS_SMALL4_WIDE_F64 || N4 <= 4) ? 1 : 2;
+    static constexpr int NW = ((CX || QS_SMALL4_WIDE_F64) && N4 > 4) ? 8 : 4;
 };
 
-constexpr int small4_threads(bool cx, int n4) { return (cx && n4 > 4) ? 512 : 256; }
+constexpr int small4_threads(bool cx, int n4) { return ((cx || QS_SMALL4_WIDE_F64) && n4 > 4) ? 512 : 256; }
 
 // N4 = ceil(L / 4) = ceil(M / 4), 1 ... 8
 template <bool CX, int N4>

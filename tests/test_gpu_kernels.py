@@ -132,7 +132,7 @@ def test_small_basis_kernel_is_bit_identical_to_the_16_wide_path(K, cplx):
             C = C + 1j * rng.standard_normal((L, M)) / np.sqrt(L)
             Ct = Ct + 1j * rng.standard_normal((M, L)) / np.sqrt(L)
         du, dC, dCt = dev(u), dev(C), dev(Ct)
-        auto = max(L, M) <= (24 if cplx else 16)          # where it measured faster (profiles/r03_small4.txt)
+        auto = max(L, M) <= (24 if cplx else 20)          # where it measured faster (profiles/r03_small4.txt)
         if not auto:
             K.tuning_set("small4", 2)                      # ... and wherever it exists
         try:
