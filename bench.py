@@ -539,6 +539,7 @@ def dominant_kernel(log):
             name, _, rep = item.rpartition(" x")
             if not name or not rep.isdigit():
                 name, rep = item, ""
+            name = name.replace("+tail", "")     # (a launch whose last round is split: the same kernel symbol in a profile)
             k = int(rep) if rep else 1
             if name not in counts:
                 order.append(name)
