@@ -220,6 +220,7 @@ int qs_tuning_set(const char* key, int64_t value) {
     if (!strcmp(key, "gemm_fast_shape")) { g_tune.gemm_fast_shape = (int)value; return QS_OK; }
     if (!strcmp(key, "gemm_pick")) { g_tune.gemm_pick = (int)value; return QS_OK; }
     if (!strcmp(key, "small4")) { g_tune.small4 = (int)value; return QS_OK; }
+    if (!strcmp(key, "pair4c_stream")) { g_tune.pair4c_stream = (int)value; return QS_OK; }
     if (!strcmp(key, "pair4c")) { g_tune.pair4c = (int)value; return QS_OK; }
     if (!strcmp(key, "sandwich")) { g_tune.sandwich = (int)value; return QS_OK; }
     if (!strcmp(key, "sandwich_mode")) { g_tune.sandwich_mode = (int)value; return QS_OK; }
@@ -302,11 +303,11 @@ static int transform_two_body_impl(int in_dtype, int dtype, const void* u, const
     }
 
     // complex128 up to 56 orbitals: the same two passes with two items per matrix instruction (qs_pair4c.hip).  Automatic
-    // where it measured faster than the four 16-wide passes (same-box sweeps, profiles/r03_pair4c.txt): 25 ... 48 orbitals
-    // except 32 itself, 1.08-1.45x with one wave per column group (section 4); from 49 up a wave is left with 128 registers
-    // (fourteen waves: four on a SIMD), spills, and falls behind (l = 55: 0.90x).  g_tune.pair4c == 2: wherever it exists.
+    // where it measured faster than the four 16-wide passes (same-box sweeps, profiles/r03_pair4c.txt): from 25 orbitals, all
+    // of them in the STREAMED form (section 5: item pairs through a ring of row quads, fetched ahead): 1.07-1.49x, l = 55
+    // 351 against 409 us (45.9 TFLOP/s).  g_tune.pair4c == 2: wherever it exists.
     if (in_dtype == dtype && dtype == QS_C128 && g_tune.pair4c && L <= 56 && M <= 56 && n4s == cdiv(M, 4) &&
-        (g_tune.pair4c == 2 || (n4s >= 7 && n4s <= 12 && !(L == 32 && M == 32)))) {
+        (g_tune.pair4c == 2 || n4s >= 7)) {
         const int64_t MM = M * M;
         int rc1 = pair4c_try(dtype, u, WA, C, M, 1, C, 1, M, L * L, L, M, L * L, L, 1, MM, M, 1, 0, s);
         if (rc1 == QS_OK)

@@ -169,6 +169,7 @@ struct Tuning {
     int sandwich_mode = -1;      // work split of the fused passes: -1 automatic, 0 one item quad per workgroup, 1 four adjacent quads, 3 + step barrier
     int small4 = 1;              // both fused passes of a basis of <= 32 orbitals on the LDS-staged 4-wide kernel (qs_small4.hip), fp64 and
                                  // complex128: 1 automatic (fp64 up to 16, complex128 up to 24 orbitals), 2 wherever it exists (up to 32), 0 off
+    int pair4c_stream = 1;       // ... its streamed form (item pairs through a ring of row quads, from 25 orbitals): 0 never
     int pair4c = 1;              // complex128 up to 56 orbitals: both fused passes on the two-items-per-instruction kernel (qs_pair4c.hip):
                                  // 1 automatic, 2 wherever it exists, 0 off
     int sandwich = 1;            // 4-wide fused passes of a small-basis transform: 0 off, 1 both (d, c) and (b, a), 2 (d, c) only, 3 (b, a) only;

@@ -181,17 +181,28 @@ def test_complex_fused_kernel_is_bit_identical_to_the_16_wide_path(K):
         u = dev(rng.standard_normal((L,) * 4) + 1j * rng.standard_normal((L,) * 4))
         C = dev((rng.standard_normal((L, M)) + 1j * rng.standard_normal((L, M))) / np.sqrt(L))
         Ct = dev((rng.standard_normal((M, L)) + 1j * rng.standard_normal((M, L))) / np.sqrt(L))
-        auto = 25 <= max(L, M) <= 48 and min(L, M) > 24 and (L, M) != (32, 32)
+        auto = 25 <= max(L, M) <= 56 and min(L, M) > 24
         K.tuning_set("pair4c", 2)
         K.tuning_set("small4", 0)
+        K.tuning_set("pair4c_stream", 0)                    # the whole-pair form
         try:
             got = K.transform_two_body(u, C, Ct)
             ran = K.last_dispatch()
         finally:
             K.tuning_reset()
         assert ran == f"qs::pair4c_kernel<{-(-L // 4)}> x2", (L, M, ran)
+        if max(L, M) > 24:                                  # the streamed form (item pairs through a ring of row quads)
+            K.tuning_set("pair4c", 2)
+            K.tuning_set("pair4c_stream", 2)
+            try:
+                streamed = K.transform_two_body(u, C, Ct)
+                ran = K.last_dispatch()
+            finally:
+                K.tuning_reset()
+            assert ran == f"qs::pair4s_kernel<{-(-L // 4)}> x2", (L, M, ran)
+            assert torch.equal(streamed, got), (L, M)
         K.transform_two_body(u, C, Ct)
-        assert ("pair4c" in K.last_dispatch()) == auto, (L, M, K.last_dispatch())
+        assert ("pair4" in K.last_dispatch()) == auto, (L, M, K.last_dispatch())
         K.tuning_set("pair4c", 0)
         K.tuning_set("small4", 0)
         try:
