@@ -220,6 +220,7 @@ int qs_tuning_set(const char* key, int64_t value) {
     if (!strcmp(key, "gemm_fast_shape")) { g_tune.gemm_fast_shape = (int)value; return QS_OK; }
     if (!strcmp(key, "gemm_pick")) { g_tune.gemm_pick = (int)value; return QS_OK; }
     if (!strcmp(key, "small4")) { g_tune.small4 = (int)value; return QS_OK; }
+    if (!strcmp(key, "quad4s")) { g_tune.quad4s = (int)value; return QS_OK; }
     if (!strcmp(key, "pair4c_stream")) { g_tune.pair4c_stream = (int)value; return QS_OK; }
     if (!strcmp(key, "pair4c")) { g_tune.pair4c = (int)value; return QS_OK; }
     if (!strcmp(key, "sandwich")) { g_tune.sandwich = (int)value; return QS_OK; }
@@ -267,6 +268,12 @@ int64_t qs_transform_two_body_workspace(int dtype, int64_t L, int64_t M) {
 
 namespace qs {
 // qs_transform_two_body / qs_transform_two_body_mixed: `in_dtype` is the type of u, `dtype` that of C, Ct and out
+
+// where the streamed fp64 kernel measured faster than the other small-basis paths (profiles/r03_quad4s.txt)
+// (17 ... 32 orbitals: 1.12-1.21x over qs_small4.hip / the 16-wide kernels, l = 20 10.2 -> 9.1 us, 32 22.4 -> 19.8; from 33
+// the hand-scheduled qs_sandwich4*.hip stay ahead, 0.72-0.86x)
+static bool quad4s_wins(int64_t L, int64_t M) { return L <= 32 && M <= 32; }
+
 static int transform_two_body_impl(int in_dtype, int dtype, const void* u, const void* C, const void* Ct, void* out,
                                    void* work, int64_t work_bytes, int64_t L, int64_t M, void* stream) {
     dispatch_reset();
@@ -289,16 +296,27 @@ static int transform_two_body_impl(int in_dtype, int dtype, const void* u, const
     // up to 32 orbitals, both dtypes: two launches of the LDS-staged kernel (what is left below ~33 orbitals is launches, not
     // work: the 16-wide kernels need three to five); T2 (L, L, M, M) in WA
     // (same-box sweep with the launches of a transform captured in one graph, profiles/r03_small4.txt: 1.8-2.9x up to 15
-    // orbitals for both dtypes, 1.1-1.4x for complex128 up to 24, 1.04x for fp64 at 17 ... 20 with eight waves; fp64 from 21
-    // and complex128 from 25 orbitals level with the 16-wide kernels or behind them -- what the kernel waits for there is the one round trip of its loads and the
+    // orbitals for both dtypes, 1.1-1.4x for complex128 up to 24; fp64 from 17 orbitals runs the streamed kernel below,
+    // complex128 from 25 the streamed pair kernel -- what the kernel waits for there is the one round trip of its loads and the
     // drain of its stores, with one workgroup per CU and nothing to overlap them with.  g_tune.small4 == 2: wherever it exists)
     const int64_t n4s = cdiv(L, 4);
     if (in_dtype == dtype && g_tune.small4 && L <= 32 && M <= 32 && n4s == cdiv(M, 4) &&
-        (g_tune.small4 == 2 || n4s <= (dtype == QS_C128 ? 6 : 5))) {
+        (g_tune.small4 == 2 || n4s <= (dtype == QS_C128 ? 6 : 4))) {
         const int64_t MM = M * M;
         int rc1 = small4_try(dtype, u, WA, C, M, 1, C, 1, M, L * L, L, M, L * L, L, 1, MM, M, 1, 0, s);
         if (rc1 == QS_OK)
             rc1 = small4_try(dtype, WA, out, Ct, 1, L, Ct, L, 1, MM, L, M, 1, L * MM, MM, 1, M * MM, MM, 1, s);
+        if (rc1 != 1) return rc1;
+    }
+
+    // fp64, 17 ... 64 orbitals: the two passes on the streamed kernel (qs_quad4s.hip) where it measured faster than what
+    // follows (profiles/r03_quad4s.txt).  g_tune.quad4s == 2: wherever it exists.
+    if (in_dtype == dtype && dtype == QS_F64 && g_tune.quad4s && L >= 17 && M >= 17 && L <= 64 && M <= 64 && n4s == cdiv(M, 4) &&
+        (g_tune.quad4s == 2 || (quad4s_wins(L, M) && g_tune.sandwich < 4))) {       // (sandwich >= 4: tuning runs of those kernels)
+        const int64_t MM = M * M;
+        int rc1 = quad4s_try(dtype, u, WA, C, M, 1, C, 1, M, L * L, L, M, L * L, L, 1, MM, M, 1, s);
+        if (rc1 == QS_OK)
+            rc1 = quad4s_try(dtype, WA, out, Ct, 1, L, Ct, L, 1, MM, L, M, 1, L * MM, MM, 1, M * MM, MM, s);
         if (rc1 != 1) return rc1;
     }
 

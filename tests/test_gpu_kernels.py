@@ -132,7 +132,7 @@ def test_small_basis_kernel_is_bit_identical_to_the_16_wide_path(K, cplx):
             C = C + 1j * rng.standard_normal((L, M)) / np.sqrt(L)
             Ct = Ct + 1j * rng.standard_normal((M, L)) / np.sqrt(L)
         du, dC, dCt = dev(u), dev(C), dev(Ct)
-        auto = max(L, M) <= (24 if cplx else 20)          # where it measured faster (profiles/r03_small4.txt)
+        auto = max(L, M) <= (24 if cplx else 16)          # where it measured faster (profiles/r03_small4.txt)
         if not auto:
             K.tuning_set("small4", 2)                      # ... and wherever it exists
         try:
@@ -167,6 +167,36 @@ def test_small_basis_kernel_is_bit_identical_to_the_16_wide_path(K, cplx):
     Cn = rng.standard_normal((L, L))
     got = K.transform_two_body(big[:L], dev(Cn))
     assert "small4" in K.last_dispatch() and torch.isfinite(got).all()
+    assert relerr(host(got), orc.transform_two_body(uu, Cn)) <= RTOL
+
+
+def test_streamed_fp64_kernel_is_bit_identical_to_the_16_wide_path(K):
+    # qs_quad4s.hip: both fused passes of a REAL basis of 17 ... 64 orbitals, item quads streamed through a ring of row quads,
+    # one wave per column group; the same k-ordered chains as the 16-wide kernels.  Automatic for 17 ... 32 orbitals.
+    rng = np.random.default_rng(91)
+    shapes = [(l, l) for l in (17, 19, 20, 21, 24, 25, 27, 28, 29, 31, 32, 33, 36, 39, 41, 45, 48, 50, 53, 55, 56, 57, 60, 63, 64)]
+    shapes += [(18, 20), (20, 17), (30, 32), (32, 29), (55, 53), (62, 64)]             # rectangular within one quad count
+    for (L, M) in shapes:
+        u = dev(rng.standard_normal((L,) * 4))
+        C = dev(rng.standard_normal((L, M)) / np.sqrt(L))
+        Ct = dev(rng.standard_normal((M, L)) / np.sqrt(L))
+        with K.tuning(quad4s=2, small4=0):
+            got = K.transform_two_body(u, C, Ct)
+            assert K.last_dispatch() == f"qs::quad4s_kernel<{-(-L // 4)}> x2", (L, M, K.last_dispatch())
+        with K.tuning(quad4s=0, small4=0, sandwich=0):
+            wide = K.transform_two_body(u, C, Ct)
+            assert "quad4s" not in K.last_dispatch() and "sandwich4" not in K.last_dispatch() and "small4" not in K.last_dispatch()
+        assert torch.equal(got, wide), (L, M)
+        K.transform_two_body(u, C, Ct)
+        assert ("quad4s" in K.last_dispatch()) == (max(L, M) <= 32), (L, M, K.last_dispatch())
+    # an item count that is not a multiple of four next to poisoned memory, and non-finite values staying in their slabs
+    L = 21
+    big = torch.full((L + 1, L, L, L), float("nan"), dtype=torch.float64, device="cuda")
+    uu = rng.standard_normal((L,) * 4)
+    big[:L] = dev(uu)
+    Cn = rng.standard_normal((L, L))
+    got = K.transform_two_body(big[:L], dev(Cn))
+    assert "quad4s" in K.last_dispatch() and torch.isfinite(got).all()
     assert relerr(host(got), orc.transform_two_body(uu, Cn)) <= RTOL
 
 
