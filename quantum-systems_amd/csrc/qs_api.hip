@@ -270,9 +270,9 @@ namespace qs {
 // qs_transform_two_body / qs_transform_two_body_mixed: `in_dtype` is the type of u, `dtype` that of C, Ct and out
 
 // where the streamed fp64 kernel measured faster than the other small-basis paths (profiles/r03_quad4s.txt)
-// (17 ... 32 orbitals: 1.12-1.21x over qs_small4.hip / the 16-wide kernels, l = 20 10.2 -> 9.1 us, 32 22.4 -> 19.8; from 33
+// (9 ... 16 orbitals: 1.06-1.14x over qs_small4.hip; 17 ... 32: 1.12-1.21x over it / the 16-wide kernels, l = 20 10.2 -> 9.1 us, 32 22.4 -> 19.8; from 33
 // the hand-scheduled qs_sandwich4*.hip stay ahead, 0.72-0.86x)
-static bool quad4s_wins(int64_t L, int64_t M) { return L <= 32 && M <= 32; }
+static bool quad4s_wins(int64_t L, int64_t M) { return L >= 9 && M >= 9 && L <= 32 && M <= 32; }
 
 static int transform_two_body_impl(int in_dtype, int dtype, const void* u, const void* C, const void* Ct, void* out,
                                    void* work, int64_t work_bytes, int64_t L, int64_t M, void* stream) {
@@ -296,12 +296,12 @@ static int transform_two_body_impl(int in_dtype, int dtype, const void* u, const
     // up to 32 orbitals, both dtypes: two launches of the LDS-staged kernel (what is left below ~33 orbitals is launches, not
     // work: the 16-wide kernels need three to five); T2 (L, L, M, M) in WA
     // (same-box sweep with the launches of a transform captured in one graph, profiles/r03_small4.txt: 1.8-2.9x up to 15
-    // orbitals for both dtypes, 1.1-1.4x for complex128 up to 24; fp64 from 17 orbitals runs the streamed kernel below,
-    // complex128 from 25 the streamed pair kernel -- what the kernel waits for there is the one round trip of its loads and the
+    // orbitals for both dtypes, 1.1-1.4x for complex128 up to 24.  Since the streamed kernels exist (below: the loads of the
+    // next items under the products of these) it is the automatic choice only up to 8 orbitals (fp64) / 4 (complex128) -- what the kernel waits for there is the one round trip of its loads and the
     // drain of its stores, with one workgroup per CU and nothing to overlap them with.  g_tune.small4 == 2: wherever it exists)
     const int64_t n4s = cdiv(L, 4);
     if (in_dtype == dtype && g_tune.small4 && L <= 32 && M <= 32 && n4s == cdiv(M, 4) &&
-        (g_tune.small4 == 2 || n4s <= (dtype == QS_C128 ? 6 : 4))) {
+        (g_tune.small4 == 2 || n4s <= (dtype == QS_C128 ? 1 : 2))) {
         const int64_t MM = M * M;
         int rc1 = small4_try(dtype, u, WA, C, M, 1, C, 1, M, L * L, L, M, L * L, L, 1, MM, M, 1, 0, s);
         if (rc1 == QS_OK)
@@ -311,7 +311,7 @@ static int transform_two_body_impl(int in_dtype, int dtype, const void* u, const
 
     // fp64, 17 ... 64 orbitals: the two passes on the streamed kernel (qs_quad4s.hip) where it measured faster than what
     // follows (profiles/r03_quad4s.txt).  g_tune.quad4s == 2: wherever it exists.
-    if (in_dtype == dtype && dtype == QS_F64 && g_tune.quad4s && L >= 17 && M >= 17 && L <= 64 && M <= 64 && n4s == cdiv(M, 4) &&
+    if (in_dtype == dtype && dtype == QS_F64 && g_tune.quad4s && L >= 5 && M >= 5 && L <= 64 && M <= 64 && n4s == cdiv(M, 4) &&
         (g_tune.quad4s == 2 || (quad4s_wins(L, M) && g_tune.sandwich < 4))) {       // (sandwich >= 4: tuning runs of those kernels)
         const int64_t MM = M * M;
         int rc1 = quad4s_try(dtype, u, WA, C, M, 1, C, 1, M, L * L, L, M, L * L, L, 1, MM, M, 1, s);
@@ -321,11 +321,12 @@ static int transform_two_body_impl(int in_dtype, int dtype, const void* u, const
     }
 
     // complex128 up to 56 orbitals: the same two passes with two items per matrix instruction (qs_pair4c.hip).  Automatic
-    // where it measured faster than the four 16-wide passes (same-box sweeps, profiles/r03_pair4c.txt): from 25 orbitals, all
-    // of them in the STREAMED form (section 5: item pairs through a ring of row quads, fetched ahead): 1.07-1.49x, l = 55
-    // 351 against 409 us (45.9 TFLOP/s).  g_tune.pair4c == 2: wherever it exists.
-    if (in_dtype == dtype && dtype == QS_C128 && g_tune.pair4c && L <= 56 && M <= 56 && n4s == cdiv(M, 4) &&
-        (g_tune.pair4c == 2 || n4s >= 7)) {
+    // where it measured faster than qs_small4.hip / the four 16-wide passes (same-box sweeps, profiles/r03_pair4c.txt): from 5
+    // orbitals, all of them in the STREAMED form (section 5: item pairs through a ring of row quads, fetched ahead): 1.07-1.56x
+    // (l = 20 17.2 -> 12.0 us, l = 55 409 -> 351 us = 45.9 TFLOP/s); 57 ... 64 orbitals exist but spill and lose.
+    // g_tune.pair4c == 2: wherever it exists.
+    if (in_dtype == dtype && dtype == QS_C128 && g_tune.pair4c && L <= 64 && M <= 64 && n4s == cdiv(M, 4) &&
+        (g_tune.pair4c == 2 || (n4s >= 2 && n4s <= 14))) {
         const int64_t MM = M * M;
         int rc1 = pair4c_try(dtype, u, WA, C, M, 1, C, 1, M, L * L, L, M, L * L, L, 1, MM, M, 1, 0, s);
         if (rc1 == QS_OK)

@@ -345,7 +345,7 @@ __global__ __launch_bounds__(64 * stream_waves(N4)) void pair4s_kernel(const Pai
     constexpr int PLANE = 2 * ITEM + 2;          // == 2 mod 32
     constexpr int SLOT = 2 * PLANE;
     constexpr int TABLE = N4 * N4 * 16;
-    constexpr int P = 3;                         // row quads in flight between their fetch and the ring
+    constexpr int P = N4 > 3 ? 3 : N4 - 1;       // row quads in flight between their fetch and the ring
     static_assert(8 * K4 <= NTH, "one element per thread and row quad");
     static_assert(P < N4, "a fetch reaches into the next pair at most");
     extern __shared__ __attribute__((aligned(16))) double lds[];
@@ -473,7 +473,7 @@ __global__ __launch_bounds__(64 * stream_waves(N4)) void pair4s_kernel(const Pai
                 p1 = ltab[TABLE + f + e_lane];
             }
         };
-        constexpr int AHEAD = NJ == 1 ? 2 : 1;              // groups between the read of the operands and their MFMAs
+        constexpr int AHEAD = (NJ == 1 && N4 > 2) ? 2 : 1;  // groups between the read of the operands and their MFMAs
         static_assert(AHEAD < N4, "the read-ahead of a step's last groups stays behind its barrier");
         double opr[AHEAD + 1][2];
         unroll<0, AHEAD>([&](auto T) __attribute__((always_inline)) {
@@ -602,7 +602,7 @@ int pair4c_try(int dtype, const void* in, void* out, const void* R, int64_t r_sk
                int64_t l_sp, int64_t l_sa, int64_t nitems, int64_t L, int64_t M, int64_t in_item, int64_t in_row,
                int64_t in_col, int64_t out_item, int64_t out_row, int64_t out_col, int tensor_is_b, hipStream_t stream) {
     if (dtype != QS_C128) return 1;
-    if (L < 1 || M < 1 || L > 56 || M > 56) return 1;
+    if (L < 1 || M < 1 || L > 64 || M > 64) return 1;       // (57 ... 64 orbitals: the streamed form only)
     const int n4 = (int)cdiv(L, 4);
     if (n4 != (int)cdiv(M, 4)) return 1;
     if (nitems < 1 || nitems >= (int64_t(1) << 31)) return 1;
@@ -622,16 +622,25 @@ int pair4c_try(int dtype, const void* in, void* out, const void* R, int64_t r_sk
     if (g_tune.pair4c_stream >= 1) {         // (faster at every size it exists for, 25 ... 56 orbitals)
         switch (n4) {
 #define QS_PAIR4S_CASE(N) case N: { const int rc = launch_pair4s<N>(g, stream); if (rc != 1) return rc; break; }
-            QS_PAIR4S_CASE(7) QS_PAIR4S_CASE(8) QS_PAIR4S_CASE(9) QS_PAIR4S_CASE(10) QS_PAIR4S_CASE(11) QS_PAIR4S_CASE(12)
-            QS_PAIR4S_CASE(13) QS_PAIR4S_CASE(14)
+#ifdef QS_DEV_FEW_SHAPES      // development / sanitizer builds of the HOST side: one instantiation
+            QS_PAIR4S_CASE(7)
+#else
+            QS_PAIR4S_CASE(2) QS_PAIR4S_CASE(3) QS_PAIR4S_CASE(4) QS_PAIR4S_CASE(5) QS_PAIR4S_CASE(6) QS_PAIR4S_CASE(7) QS_PAIR4S_CASE(8) QS_PAIR4S_CASE(9)
+            QS_PAIR4S_CASE(10) QS_PAIR4S_CASE(11) QS_PAIR4S_CASE(12) QS_PAIR4S_CASE(13) QS_PAIR4S_CASE(14) QS_PAIR4S_CASE(15)
+            QS_PAIR4S_CASE(16)
+#endif
 #undef QS_PAIR4S_CASE
             default: break;
         }
     }
     switch (n4) {
 #define QS_PAIR4C_CASE(N) case N: return launch_pair4c<N>(g, stream);
+#ifdef QS_DEV_FEW_SHAPES
+        QS_PAIR4C_CASE(7)
+#else
         QS_PAIR4C_CASE(1) QS_PAIR4C_CASE(2) QS_PAIR4C_CASE(3) QS_PAIR4C_CASE(4) QS_PAIR4C_CASE(5) QS_PAIR4C_CASE(6) QS_PAIR4C_CASE(7)
         QS_PAIR4C_CASE(8) QS_PAIR4C_CASE(9) QS_PAIR4C_CASE(10) QS_PAIR4C_CASE(11) QS_PAIR4C_CASE(12) QS_PAIR4C_CASE(13) QS_PAIR4C_CASE(14)
+#endif
 #undef QS_PAIR4C_CASE
         default: return 1;
     }

@@ -58,7 +58,7 @@ __device__ __forceinline__ double mfma4q(double a, double b, double c) {
 
 }  // namespace
 
-// N4 = ceil(L / 4) = ceil(M / 4), 5 ... 16
+// N4 = ceil(L / 4) = ceil(M / 4), 2 ... 16
 template <int N4>
 __global__ __launch_bounds__(64 * N4) void quad4s_kernel(const Quad4Args g) {
     constexpr int NTH = 64 * N4;
@@ -67,7 +67,7 @@ __global__ __launch_bounds__(64 * N4) void quad4s_kernel(const Quad4Args g) {
     constexpr int PLANE = 2 * ITEM + 2;          // == 2 mod 32
     constexpr int SLOT = 2 * PLANE;
     constexpr int TABLE = N4 * N4 * 16;
-    constexpr int P = 3;                         // row quads in flight between their fetch and the ring
+    constexpr int P = N4 > 3 ? 3 : N4 - 1;       // row quads in flight between their fetch and the ring
     static_assert(8 * K4 <= NTH, "one 16-byte element pair per thread and row quad");
     static_assert(P < N4, "a fetch reaches into the next quad at most");
     extern __shared__ __attribute__((aligned(16))) double lds[];
@@ -187,7 +187,7 @@ __global__ __launch_bounds__(64 * N4) void quad4s_kernel(const Quad4Args g) {
             if constexpr (gi < N4) return ring[a_of[ka & 1] + 4 * gi];
             else return ltab[((gi - N4) * N4 + ka) * 16 + e_lane];
         };
-        constexpr int AHEAD = 3;                            // groups between the read of an operand and its MFMA
+        constexpr int AHEAD = N4 > 3 ? 3 : N4 - 1;          // groups between the read of an operand and its MFMA
         static_assert(AHEAD < N4, "the read-ahead of a step's last groups stays behind its barrier");
         double opr[AHEAD + 1];
         unroll_q<0, AHEAD>([&](auto T) __attribute__((always_inline)) { opr[decltype(T)::value % (AHEAD + 1)] = operand(T); });
@@ -270,7 +270,7 @@ int quad4s_try(int dtype, const void* in, void* out, const void* R, int64_t r_sk
                int64_t l_sp, int64_t l_sa, int64_t nitems, int64_t L, int64_t M, int64_t in_item, int64_t in_row,
                int64_t in_col, int64_t out_item, int64_t out_row, int64_t out_col, hipStream_t stream) {
     if (dtype != QS_F64) return 1;
-    if (L < 17 || M < 17 || L > 64 || M > 64) return 1;
+    if (L < 5 || M < 5 || L > 64 || M > 64) return 1;
     const int n4 = (int)cdiv(L, 4);
     if (n4 != (int)cdiv(M, 4)) return 1;
     if (nitems < 1 || nitems >= (int64_t(1) << 31)) return 1;
@@ -290,8 +290,12 @@ int quad4s_try(int dtype, const void* in, void* out, const void* R, int64_t r_sk
     g.nquads = (unsigned)cdiv(nitems, 4);
     switch (n4) {
 #define QS_QUAD4S_CASE(N) case N: return launch_quad4s<N>(g, stream);
-        QS_QUAD4S_CASE(5) QS_QUAD4S_CASE(6) QS_QUAD4S_CASE(7) QS_QUAD4S_CASE(8) QS_QUAD4S_CASE(9) QS_QUAD4S_CASE(10)
+#ifdef QS_DEV_FEW_SHAPES      // development / sanitizer builds of the HOST side: one instantiation
+        QS_QUAD4S_CASE(5)
+#else
+        QS_QUAD4S_CASE(2) QS_QUAD4S_CASE(3) QS_QUAD4S_CASE(4) QS_QUAD4S_CASE(5) QS_QUAD4S_CASE(6) QS_QUAD4S_CASE(7) QS_QUAD4S_CASE(8) QS_QUAD4S_CASE(9) QS_QUAD4S_CASE(10)
         QS_QUAD4S_CASE(11) QS_QUAD4S_CASE(12) QS_QUAD4S_CASE(13) QS_QUAD4S_CASE(14) QS_QUAD4S_CASE(15) QS_QUAD4S_CASE(16)
+#endif
 #undef QS_QUAD4S_CASE
         default: return 1;
     }

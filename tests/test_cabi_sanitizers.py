@@ -38,7 +38,8 @@ def test_argument_paths_under_asan_and_ubsan(tmp_path):
 
     with ThreadPoolExecutor(max_workers=4) as pool:
         objs = list(pool.map(compile_one, srcs))
-    res = subprocess.run([HIPCC, "--offload-arch=gfx950", *objs, "-fsanitize=address,undefined", "-ldl", "-o", str(exe)],
+    host_link = ["-Xarch_host", "-fsanitize=address,undefined"]       # (the host pass only, as in the compile steps)
+    res = subprocess.run([HIPCC, "--offload-arch=gfx950", *objs, *host_link, "-ldl", "-o", str(exe)],
                          capture_output=True, text=True, timeout=900)
     assert res.returncode == 0, res.stderr[-3000:]
     sym = subprocess.run(["nm", str(exe)], capture_output=True, text=True).stdout

@@ -132,7 +132,7 @@ def test_small_basis_kernel_is_bit_identical_to_the_16_wide_path(K, cplx):
             C = C + 1j * rng.standard_normal((L, M)) / np.sqrt(L)
             Ct = Ct + 1j * rng.standard_normal((M, L)) / np.sqrt(L)
         du, dC, dCt = dev(u), dev(C), dev(Ct)
-        auto = max(L, M) <= (24 if cplx else 16)          # where it measured faster (profiles/r03_small4.txt)
+        auto = max(L, M) <= (4 if cplx else 8)            # (above: the streamed kernels, qs_quad4s.hip / pair4s_kernel)
         if not auto:
             K.tuning_set("small4", 2)                      # ... and wherever it exists
         try:
@@ -174,8 +174,9 @@ def test_streamed_fp64_kernel_is_bit_identical_to_the_16_wide_path(K):
     # qs_quad4s.hip: both fused passes of a REAL basis of 17 ... 64 orbitals, item quads streamed through a ring of row quads,
     # one wave per column group; the same k-ordered chains as the 16-wide kernels.  Automatic for 17 ... 32 orbitals.
     rng = np.random.default_rng(91)
-    shapes = [(l, l) for l in (17, 19, 20, 21, 24, 25, 27, 28, 29, 31, 32, 33, 36, 39, 41, 45, 48, 50, 53, 55, 56, 57, 60, 63, 64)]
-    shapes += [(18, 20), (20, 17), (30, 32), (32, 29), (55, 53), (62, 64)]             # rectangular within one quad count
+    shapes = [(l, l) for l in (5, 8, 9, 11, 12, 13, 16, 17, 19, 20, 21, 24, 25, 27, 28, 29, 31, 32, 33, 36, 39, 41, 45, 48, 50, 53,
+                               55, 56, 57, 60, 63, 64)]
+    shapes += [(7, 5), (10, 12), (18, 20), (20, 17), (30, 32), (32, 29), (55, 53), (62, 64)]     # rectangular within one quad count
     for (L, M) in shapes:
         u = dev(rng.standard_normal((L,) * 4))
         C = dev(rng.standard_normal((L, M)) / np.sqrt(L))
@@ -188,7 +189,7 @@ def test_streamed_fp64_kernel_is_bit_identical_to_the_16_wide_path(K):
             assert "quad4s" not in K.last_dispatch() and "sandwich4" not in K.last_dispatch() and "small4" not in K.last_dispatch()
         assert torch.equal(got, wide), (L, M)
         K.transform_two_body(u, C, Ct)
-        assert ("quad4s" in K.last_dispatch()) == (max(L, M) <= 32), (L, M, K.last_dispatch())
+        assert ("quad4s" in K.last_dispatch()) == (9 <= min(L, M) and max(L, M) <= 32), (L, M, K.last_dispatch())
     # an item count that is not a multiple of four next to poisoned memory, and non-finite values staying in their slabs
     L = 21
     big = torch.full((L + 1, L, L, L), float("nan"), dtype=torch.float64, device="cuda")
@@ -206,12 +207,12 @@ def test_complex_fused_kernel_is_bit_identical_to_the_16_wide_path(K):
     rng = np.random.default_rng(77)
     shapes = [(25, 25), (28, 27), (29, 32), (32, 32), (33, 33), (36, 34), (37, 40), (41, 44), (47, 45), (48, 48), (49, 52), (55, 55),
               (56, 53)]
-    small = [(3, 3), (8, 6), (13, 16), (21, 24)]            # (qs_small4.hip is the automatic choice there)
+    small = [(3, 3), (8, 6), (13, 16), (21, 24)]
     for (L, M) in shapes + small:
         u = dev(rng.standard_normal((L,) * 4) + 1j * rng.standard_normal((L,) * 4))
         C = dev((rng.standard_normal((L, M)) + 1j * rng.standard_normal((L, M))) / np.sqrt(L))
         Ct = dev((rng.standard_normal((M, L)) + 1j * rng.standard_normal((M, L))) / np.sqrt(L))
-        auto = 25 <= max(L, M) <= 56 and min(L, M) > 24
+        auto = 5 <= max(L, M) <= 56                        # (up to 4 orbitals: qs_small4.hip)
         K.tuning_set("pair4c", 2)
         K.tuning_set("small4", 0)
         K.tuning_set("pair4c_stream", 0)                    # the whole-pair form
@@ -221,7 +222,7 @@ def test_complex_fused_kernel_is_bit_identical_to_the_16_wide_path(K):
         finally:
             K.tuning_reset()
         assert ran == f"qs::pair4c_kernel<{-(-L // 4)}> x2", (L, M, ran)
-        if max(L, M) > 24:                                  # the streamed form (item pairs through a ring of row quads)
+        if max(L, M) > 4:                                   # the streamed form (item pairs through a ring of row quads)
             K.tuning_set("pair4c", 2)
             K.tuning_set("pair4c_stream", 2)
             try:
@@ -251,7 +252,10 @@ def test_complex_fused_kernel_is_bit_identical_to_the_16_wide_path(K):
     K.tuning_set("small4", 0)
     try:
         got = K.transform_two_body(big[:L], dev(Cn))
-        assert "pair4c" in K.last_dispatch() and torch.isfinite(torch.view_as_real(got)).all()
+        assert "pair4s" in K.last_dispatch() and torch.isfinite(torch.view_as_real(got)).all()
+        K.tuning_set("pair4c_stream", 0)                    # (and the whole-pair form)
+        got0 = K.transform_two_body(big[:L], dev(Cn))
+        assert "pair4c" in K.last_dispatch() and torch.equal(got0, got)
     finally:
         K.tuning_reset()
     assert relerr(host(got), orc.transform_two_body(uu, Cn)) <= RTOL

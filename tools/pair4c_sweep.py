@@ -52,6 +52,8 @@ for l in sizes:
     out = torch.empty_like(u)
     reps = 40 if l <= 32 else 10
     K.tuning_set("pair4c", 2)
+    if os.environ.get("QS_PAIR4C_NO_SMALL4"):               # (up to 24 orbitals qs_small4.hip is asked first)
+        K.tuning_set("small4", 0)
     if os.environ.get("QS_PAIR4C_STREAM"):                  # 0 whole-pair form, 2 streamed form wherever it exists
         K.tuning_set("pair4c_stream", int(os.environ["QS_PAIR4C_STREAM"]))
     a = K.transform_two_body(u, C, Ct).clone()
