@@ -336,6 +336,18 @@ static int transform_two_body_impl(int in_dtype, int dtype, const void* u, const
 
     // small bases: two passes over the tensor instead of four -- (d, c) per slab u[a, b], then (b, a) per
     // column (r, s): out[:, :, rs] = Ct . T2[:, :, rs] . Ct^T (the same k-ordered sums, element for element)
+    // a REAL tensor against complex coefficients (qs_transform_two_body_mixed), 5 ... 56 orbitals: the streamed pair kernel with
+    // real items for the first pass (its first product is one MFMA per fragment instead of two), the complex one for the second
+    // (tools/mixed_small.py: the tiled route took 22.7 us at l = 20 where a complex tensor takes 13.3).
+    if (in_dtype == QS_F64 && dtype == QS_C128 && g_tune.pair4c && L >= 5 && M >= 5 && L <= 56 && M <= 56 &&
+        n4s == cdiv(M, 4)) {
+        const int64_t MM = M * M;
+        int rc1 = pair4m_try(u, WA, C, M, 1, C, 1, M, L * L, L, M, L * L, L, 1, MM, M, 1, s);
+        if (rc1 == QS_OK)
+            rc1 = pair4c_try(dtype, WA, out, Ct, 1, L, Ct, L, 1, MM, L, M, 1, L * MM, MM, 1, M * MM, MM, 1, s);
+        if (rc1 != 1) return rc1;
+    }
+
     if (in_dtype == dtype && (g_tune.sandwich == 1 || g_tune.sandwich == 3 || g_tune.sandwich == 4 || g_tune.sandwich == 6)) {
         // T2 (L, L, M, M) goes to WA; the eligibility of the second pass is known before the first runs
         const int64_t MM = M * M;

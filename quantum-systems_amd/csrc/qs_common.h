@@ -122,11 +122,15 @@ int small4_try(int dtype, const void* in, void* out, const void* R, int64_t r_sk
                int64_t l_sp, int64_t l_sa, int64_t nitems, int64_t L, int64_t M, int64_t in_item, int64_t in_row,
                int64_t in_col, int64_t out_item, int64_t out_row, int64_t out_col, int tensor_is_b, hipStream_t stream);
 
+// ... and for REAL items against complex R and Lm (the first pass of a real tensor against complex coefficients), streamed form only
+int pair4m_try(const void* in, void* out, const void* R, int64_t r_sk, int64_t r_sj, const void* Lm, int64_t l_sp, int64_t l_sa,
+               int64_t nitems, int64_t L, int64_t M, int64_t in_item, int64_t in_row, int64_t in_col, int64_t out_item,
+               int64_t out_row, int64_t out_col, hipStream_t stream);
 // fp64, 17 ... 64 orbitals, streamed (qs_quad4s.hip): item quads through a ring of row quads, one wave per column group.
 int quad4s_try(int dtype, const void* in, void* out, const void* R, int64_t r_sk, int64_t r_sj, const void* Lm,
                int64_t l_sp, int64_t l_sa, int64_t nitems, int64_t L, int64_t M, int64_t in_item, int64_t in_row,
                int64_t in_col, int64_t out_item, int64_t out_row, int64_t out_col, hipStream_t stream);
-// The same for complex128 up to 56 orbitals (qs_pair4c.hip): two items per matrix instruction, blocks = (item, re | im).
+// The same for complex128, 5 ... 64 orbitals (qs_pair4s.h, qs_pair4c.hip): two items per matrix instruction, blocks = (item, re | im), streamed.
 int pair4c_try(int dtype, const void* in, void* out, const void* R, int64_t r_sk, int64_t r_sj, const void* Lm,
                int64_t l_sp, int64_t l_sa, int64_t nitems, int64_t L, int64_t M, int64_t in_item, int64_t in_row,
                int64_t in_col, int64_t out_item, int64_t out_row, int64_t out_col, int tensor_is_b, hipStream_t stream);
@@ -174,7 +178,7 @@ struct Tuning {
     int small4 = 1;              // both fused passes of a basis of <= 32 orbitals on the LDS-staged 4-wide kernel (qs_small4.hip), fp64 and
                                  // complex128: 1 automatic (fp64 up to 16, complex128 up to 24 orbitals), 2 wherever it exists (up to 32), 0 off
     int quad4s = 1;              // fp64 17 ... 64 orbitals on the streamed fused kernel (qs_quad4s.hip): 0 never, 1 where measured faster, 2 wherever it exists
-    int pair4c_stream = 1;       // ... its streamed form (item pairs through a ring of row quads, from 25 orbitals): 0 never
+    int pair4c_stream = 1;       // (kept for old tuning scripts: the whole-pair form it switched to is gone)
     int pair4c = 1;              // complex128 up to 56 orbitals: both fused passes on the two-items-per-instruction kernel (qs_pair4c.hip):
                                  // 1 automatic, 2 wherever it exists, 0 off
     int sandwich = 1;            // 4-wide fused passes of a small-basis transform: 0 off, 1 both (d, c) and (b, a), 2 (d, c) only, 3 (b, a) only;

@@ -1,0 +1,17 @@
+// Instantiations of the streamed pair kernel (qs_pair4s.h): complex items, ceil(l/4) = 15, 16
+#include "qs_pair4s.h"
+
+namespace qs {
+
+int launch_pair4s_d(int n4, const Pair4Args& g, hipStream_t stream) {
+    switch (n4) {
+#ifdef QS_DEV_FEW_SHAPES      // development / sanitizer builds of the HOST side: one instantiation
+        
+#else
+        case 15: return launch_pair4s<15>(g, stream); case 16: return launch_pair4s<16>(g, stream);
+#endif
+        default: return 1;
+    }
+}
+
+}  // namespace qs

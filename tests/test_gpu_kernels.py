@@ -75,8 +75,15 @@ def test_mixed_real_u_complex_C_runs_without_a_complex_copy_of_u(K, golden):
     u, C = dev(g["u"]), dev(g["C"])
     got = K.transform_two_body(u, C)
     ran = K.last_dispatch().split(";")
-    first = [r for r in ran if "gemm" in r][0]
-    assert "<false" in first or "gemm_kernel<" in first or "stream_left_kernel" in first, ran     # the real product first
+    if "pair4s" in ran[0]:           # small bases: the streamed fused kernel with REAL items for the first pass
+        assert ran[0].endswith(", true>") and "pair4s" in ran[1] and "true" not in ran[1], ran
+        with K.tuning(pair4c=0):     # ... bit-identical to the tiled route (real product for d, then complex)
+            tiled = K.transform_two_body(u, C)
+            assert "pair4s" not in K.last_dispatch()
+        assert torch.equal(tiled, got)
+    else:
+        first = [r for r in ran if "gemm" in r][0]
+        assert "<false" in first or "gemm_kernel<" in first or "stream_left_kernel" in first, ran     # the real product first
     assert relerr(host(got), g["u_out"]) <= RTOL
     K.mixed_real_u = False
     try:
@@ -86,13 +93,19 @@ def test_mixed_real_u_complex_C_runs_without_a_complex_copy_of_u(K, golden):
     assert (got - cast).abs().max().item() <= 1e-13 * cast.abs().max().item()
     # oracle sweep through the new route: odd sizes, rectangular both ways, explicit C~, whole tiles, the fused sizes
     rng = np.random.default_rng(33)
-    for (L, M) in ((5, 5), (9, 14), (21, 13), (40, 40), (64, 64), (55, 55), (70, 66), (128, 128)):
+    for (L, M) in ((5, 5), (9, 14), (21, 13), (13, 15), (20, 20), (31, 29), (40, 40), (47, 45), (64, 64), (55, 55), (56, 53), (70, 66),
+                   (128, 128)):
         un = rng.standard_normal((L,) * 4)
         Cn = (rng.standard_normal((L, M)) + 1j * rng.standard_normal((L, M))) / np.sqrt(L)
         Ctn = (rng.standard_normal((M, L)) + 1j * rng.standard_normal((M, L))) / np.sqrt(L)
         d_u = dev(un)
         got = K.transform_two_body(d_u, dev(Cn), dev(Ctn))
         assert got.dtype == torch.complex128
+        fused = 5 <= min(L, M) and max(L, M) <= 56 and -(-L // 4) == -(-M // 4)
+        assert ("pair4s" in K.last_dispatch()) == fused, (L, M, K.last_dispatch())
+        if fused:                    # the streamed kernel against the tiled route: the same chains
+            with K.tuning(pair4c=0):
+                assert torch.equal(K.transform_two_body(d_u, dev(Cn), dev(Ctn)), got), (L, M)
         if L <= 70:
             assert relerr(host(got), orc.transform_two_body(un, Cn, Ctn)) <= RTOL, (L, M)
         else:
@@ -202,62 +215,38 @@ def test_streamed_fp64_kernel_is_bit_identical_to_the_16_wide_path(K):
 
 
 def test_complex_fused_kernel_is_bit_identical_to_the_16_wide_path(K):
-    # qs_pair4c.hip: both fused passes of a COMPLEX128 basis of up to 56 orbitals, two items per matrix instruction (blocks =
-    # (item, re | im)); the same chains of fused multiply-adds as the four 16-wide passes, element for element.
+    # qs_pair4s.h: both fused passes of a COMPLEX128 basis of 5 ... 64 orbitals, two items per matrix instruction (blocks =
+    # (item, re | im)), item pairs streamed through a ring of row quads; the same chains of fused multiply-adds as the four
+    # 16-wide passes, element for element.  Automatic up to 56 orbitals.
     rng = np.random.default_rng(77)
-    shapes = [(25, 25), (28, 27), (29, 32), (32, 32), (33, 33), (36, 34), (37, 40), (41, 44), (47, 45), (48, 48), (49, 52), (55, 55),
-              (56, 53)]
-    small = [(3, 3), (8, 6), (13, 16), (21, 24)]
-    for (L, M) in shapes + small:
+    shapes = [(5, 5), (8, 6), (9, 11), (13, 16), (17, 17), (21, 24), (25, 25), (28, 27), (29, 32), (32, 32), (33, 33), (36, 34), (37, 40),
+              (41, 44), (47, 45), (48, 48), (49, 52), (55, 55), (56, 53), (57, 60), (64, 61)]
+    for (L, M) in shapes:
         u = dev(rng.standard_normal((L,) * 4) + 1j * rng.standard_normal((L,) * 4))
         C = dev((rng.standard_normal((L, M)) + 1j * rng.standard_normal((L, M))) / np.sqrt(L))
         Ct = dev((rng.standard_normal((M, L)) + 1j * rng.standard_normal((M, L))) / np.sqrt(L))
-        auto = 5 <= max(L, M) <= 56                        # (up to 4 orbitals: qs_small4.hip)
-        K.tuning_set("pair4c", 2)
-        K.tuning_set("small4", 0)
-        K.tuning_set("pair4c_stream", 0)                    # the whole-pair form
-        try:
+        with K.tuning(pair4c=2, small4=0):
             got = K.transform_two_body(u, C, Ct)
-            ran = K.last_dispatch()
-        finally:
-            K.tuning_reset()
-        assert ran == f"qs::pair4c_kernel<{-(-L // 4)}> x2", (L, M, ran)
-        if max(L, M) > 4:                                   # the streamed form (item pairs through a ring of row quads)
-            K.tuning_set("pair4c", 2)
-            K.tuning_set("pair4c_stream", 2)
-            try:
-                streamed = K.transform_two_body(u, C, Ct)
-                ran = K.last_dispatch()
-            finally:
-                K.tuning_reset()
-            assert ran == f"qs::pair4s_kernel<{-(-L // 4)}> x2", (L, M, ran)
-            assert torch.equal(streamed, got), (L, M)
+            assert K.last_dispatch() == f"qs::pair4s_kernel<{-(-L // 4)}> x2", (L, M, K.last_dispatch())
         K.transform_two_body(u, C, Ct)
-        assert ("pair4" in K.last_dispatch()) == auto, (L, M, K.last_dispatch())
-        K.tuning_set("pair4c", 0)
-        K.tuning_set("small4", 0)
-        try:
+        assert ("pair4s" in K.last_dispatch()) == (max(L, M) <= 56), (L, M, K.last_dispatch())
+        with K.tuning(pair4c=0, small4=0):
             wide = K.transform_two_body(u, C, Ct)
-            assert "pair4c" not in K.last_dispatch() and "small4" not in K.last_dispatch()
-        finally:
-            K.tuning_reset()
+            assert "pair4" not in K.last_dispatch() and "small4" not in K.last_dispatch()
         assert torch.equal(got, wide), (L, M)
+    # up to 4 orbitals the kernel does not exist: qs_small4.hip
+    u3 = dev(rng.standard_normal((3,) * 4) + 1j * rng.standard_normal((3,) * 4))
+    with K.tuning(pair4c=2):
+        K.transform_two_body(u3, dev(rng.standard_normal((3, 3)) + 0j))
+        assert "small4" in K.last_dispatch()
     # an odd number of items (the last pair is half empty) next to poisoned memory
     L = 5
     big = torch.full((L + 1, L, L, L), float("nan"), dtype=torch.complex128, device="cuda")
     uu = rng.standard_normal((L,) * 4) + 1j * rng.standard_normal((L,) * 4)
     big[:L] = dev(uu)
     Cn = rng.standard_normal((L, L)) + 1j * rng.standard_normal((L, L))
-    K.tuning_set("pair4c", 2)
-    K.tuning_set("small4", 0)
-    try:
-        got = K.transform_two_body(big[:L], dev(Cn))
-        assert "pair4s" in K.last_dispatch() and torch.isfinite(torch.view_as_real(got)).all()
-        K.tuning_set("pair4c_stream", 0)                    # (and the whole-pair form)
-        got0 = K.transform_two_body(big[:L], dev(Cn))
-        assert "pair4c" in K.last_dispatch() and torch.equal(got0, got)
-    finally:
-        K.tuning_reset()
+    got = K.transform_two_body(big[:L], dev(Cn))
+    assert "pair4s" in K.last_dispatch() and torch.isfinite(torch.view_as_real(got)).all()
     assert relerr(host(got), orc.transform_two_body(uu, Cn)) <= RTOL
 
 
