@@ -52,6 +52,11 @@ struct Quad4Args {
     unsigned nitems, nquads;
 };
 
+// development builds only: bit mask of parts to leave out (1 the fetches, 2 the stores, 8 the step barrier -- wrong results)
+#ifndef QS_QUAD4S_ABLATE
+#define QS_QUAD4S_ABLATE 0
+#endif
+
 __device__ __forceinline__ double mfma4q(double a, double b, double c) {
     return __builtin_amdgcn_mfma_f64_4x4x4f64(a, b, c, 0, 0, 0);
 }
@@ -66,13 +71,14 @@ __global__ __launch_bounds__(64 * N4) void quad4s_kernel(const Quad4Args g) {
     constexpr int ITEM = 4 * Lp;                 // == 16 mod 32 doubles
     constexpr int PLANE = 2 * ITEM + 2;          // == 2 mod 32
     constexpr int SLOT = 2 * PLANE;
+    constexpr int NR = 3;                        // ring slots (see the hazard note at the step barrier)
     constexpr int TABLE = N4 * N4 * 16;
     constexpr int P = N4 > 3 ? 3 : N4 - 1;       // row quads in flight between their fetch and the ring
     static_assert(8 * K4 <= NTH, "one 16-byte element pair per thread and row quad");
     static_assert(P < N4, "a fetch reaches into the next quad at most");
     extern __shared__ __attribute__((aligned(16))) double lds[];
-    double* ring = lds;                          // [2 slots][item & 1][item >> 1][4 rows][Lp]
-    double* ltab = lds + 2 * SLOT;               // [pg][ka][16]: Lm[4 pg + x][4 ka + z] at z * 4 + x
+    double* ring = lds;                          // [NR slots][item & 1][item >> 1][4 rows][Lp]
+    double* ltab = lds + NR * SLOT;              // [pg][ka][16]: Lm[4 pg + x][4 ka + z] at z * 4 + x
     const int L = g.L, M = g.M;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -122,6 +128,7 @@ __global__ __launch_bounds__(64 * N4) void quad4s_kernel(const Quad4Args g) {
     };
     auto fetch = [&](auto rs, const unsigned (&v)[2], auto KA) __attribute__((always_inline)) {
         constexpr int ka = decltype(KA)::value;
+        if constexpr (QS_QUAD4S_ABLATE & 1) return f64x2q{1.0 + ka, 0.5};
         const u32x4q q = __builtin_amdgcn_raw_buffer_load_b128(rs, (int)v[ka == N4 - 1], (int)(ka * quad_step), 0);
         return __builtin_bit_cast(f64x2q, q);
     };
@@ -131,11 +138,11 @@ __global__ __launch_bounds__(64 * N4) void quad4s_kernel(const Quad4Args g) {
             ring[w1] = shifted ? 0.0 : v.y;
         }
     };
-    // ring slot of row quad ka of the CURRENT quad: (ka & 1) ^ flip (the parity of a quad's first row quad alternates from
-    // quad to quad when N4 is odd); kept as two bases each, exchanged at the end of such a unit
-    int a_of[2], w0_of[2], w1_of[2];
+    // ring slot of row quad ka of the CURRENT quad: index ka % NR into these bases, which are rotated by N4 % NR at the end
+    // of a unit (the next quad's first row quad follows this one's last)
+    int a_of[NR], w0_of[NR], w1_of[NR];
 #pragma unroll
-    for (int sl = 0; sl < 2; ++sl) {
+    for (int sl = 0; sl < NR; ++sl) {
         a_of[sl] = sl * SLOT + (y >> 1) * ITEM + (y & 1) * PLANE + x * Lp + z;
         w0_of[sl] = sl * SLOT + f_pos0;
         w1_of[sl] = sl * SLOT + f_pos1;
@@ -179,51 +186,61 @@ __global__ __launch_bounds__(64 * N4) void quad4s_kernel(const Quad4Args g) {
     __syncthreads();
 
     for (; unit < u_end; unit += slots) {
-        double o[N4];
-        double yv = 0.0;
-        constexpr int GPK = 2 * N4;                         // groups per row quad of Y: N4 of the first product, N4 of the second
+        // Two phases per item quad (as in qs_sandwich4.hip): Y[ka] = In[ka] . R[:, group] for every row quad ka -- Y stays in
+        // the accumulators, already in B-operand layout -- then Out[pg] = sum_ka Lm[pg][ka] . Y[ka] for every row quad pg, a
+        // finished row quad of Out leaving during the next one's MFMAs.  (The first version ran both products per ka and held
+        // all of Out to the end: every workgroup of the chip stored a whole quad at once -- compiled out, those stores were
+        // 23 % of the launch at 55 orbitals and 38 % at 32, profiles/r03_quad4s.txt.)  One stream of 2 N4^2 groups, one MFMA
+        // and one LDS operand each, the operand read AHEAD groups before its MFMA.
+        double Y[N4];
+        double o2[2];
+        constexpr int NG = N4 * N4;
         auto operand = [&](auto T) __attribute__((always_inline)) {
-            constexpr int t = decltype(T)::value, ka = t / GPK, gi = t % GPK;
-            if constexpr (gi < N4) return ring[a_of[ka & 1] + 4 * gi];
-            else return ltab[((gi - N4) * N4 + ka) * 16 + e_lane];
+            constexpr int t = decltype(T)::value;
+            if constexpr (t < NG) return ring[a_of[(t / N4) % NR] + 4 * (t % N4)];                 // In[ka][ks]
+            else return ltab[(t - NG) * 16 + e_lane];                                              // Lm[pg][ka], (pg, ka) = t - NG
         };
         constexpr int AHEAD = N4 > 3 ? 3 : N4 - 1;          // groups between the read of an operand and its MFMA
-        static_assert(AHEAD < N4, "the read-ahead of a step's last groups stays behind its barrier");
+        static_assert(AHEAD < N4, "the read-ahead into the next row quad's slot starts behind the step's barrier");
         double opr[AHEAD + 1];
         unroll_q<0, AHEAD>([&](auto T) __attribute__((always_inline)) { opr[decltype(T)::value % (AHEAD + 1)] = operand(T); });
-        unroll_q<0, N4 * GPK>([&](auto T) __attribute__((always_inline)) {
-            constexpr int t = decltype(T)::value, ka = t / GPK, gi = t % GPK, sl = t % (AHEAD + 1);
-            if constexpr (gi == 0) {
+        const unsigned it_g = unit * 4 + y;                 // D: row z, block y = item, column x
+        double* orow = g.out + (int64_t)it_g * g.out_item + z * g.out_row + x * g.out_col + (int64_t)(4 * jg) * g.out_col;
+        const bool st_ok = it_g < g.nitems && 4 * jg + x < M;
+        unroll_q<0, 2 * NG>([&](auto T) __attribute__((always_inline)) {
+            constexpr int t = decltype(T)::value, sl = t % (AHEAD + 1);
+            if constexpr (t < NG && t % N4 == 0) {
                 // step start: row quad ka + 1 (the next quad's first after the last step) leaves its registers for its slot,
                 // the fetch of row quad ka + 1 + P takes its place
-                settle(w0_of[(ka + 1) & 1], w1_of[(ka + 1) & 1], pf[ka % P], ka + 1 < N4 ? sh_cur : sh_nx);
+                constexpr int ka = t / N4;
+                settle(w0_of[(ka + 1) % NR], w1_of[(ka + 1) % NR], pf[ka % P], ka + 1 < N4 ? sh_cur : sh_nx);
                 constexpr int tq = ka + 1 + P;
                 if constexpr (tq < N4) pf[ka % P] = fetch(rs_cur, v_cur, std::integral_constant<int, tq>{});
                 else pf[ka % P] = fetch(rs_nx, v_nx, std::integral_constant<int, tq - N4>{});
             }
-            if constexpr (gi == N4) {
-                // Between the two products: the step's barrier.  The slot written at the start of this step was last read in
-                // the first product of the step before, which every wave has left when any wave has passed THAT step's
-                // barrier; and it is first read -- by the operand read-ahead -- after this one.  It waits for the wave's LDS
-                // traffic only: the fetches stay in flight.
+            if constexpr (t < NG && t % N4 == 1 % N4 && !(QS_QUAD4S_ABLATE & 8)) {
+                // The step's barrier, right behind its write.  The slot written at the start of step ka holds row quad ka + 1:
+                // it is first read -- by the operand read-ahead, from group N4 - AHEAD >= 1 of this step on -- behind this
+                // barrier; and it was last read in step ka - 2, which every wave had finished when it arrived at the barrier
+                // of step ka - 1 (three slots: with two, a wave still in step ka - 1 would be reading it).  It waits for the
+                // wave's LDS traffic only: the fetches stay in flight.
                 __builtin_amdgcn_s_waitcnt(0xC07F);         // lgkmcnt(0), vmcnt / expcnt untouched
                 __builtin_amdgcn_s_barrier();
             }
-            if constexpr (t + AHEAD < N4 * GPK) opr[(t + AHEAD) % (AHEAD + 1)] = operand(std::integral_constant<int, t + AHEAD>{});
+            if constexpr (t + AHEAD < 2 * NG) opr[(t + AHEAD) % (AHEAD + 1)] = operand(std::integral_constant<int, t + AHEAD>{});
             const double cur = opr[sl];
-            if constexpr (gi < N4) yv = mfma4q(cur, bq[gi], gi == 0 ? 0.0 : yv);                 // Y[ka] += In[ka][ks] . R[ks]
-            else o[gi - N4] = mfma4q(cur, yv, ka == 0 ? 0.0 : o[gi - N4]);                       // Out[pg] += Lm[pg][ka] . Y[ka]
+            if constexpr (t < NG) {                         // Y[ka] += In[ka][ks] . R[ks]
+                constexpr int ka = t / N4, ks = t % N4;
+                Y[ka] = mfma4q(cur, bq[ks], ks == 0 ? 0.0 : Y[ka]);
+            } else {                                        // Out[pg] += Lm[pg][ka] . Y[ka]
+                constexpr int pg = (t - NG) / N4, ka = (t - NG) % N4;
+                o2[pg & 1] = mfma4q(cur, Y[ka], ka == 0 ? 0.0 : o2[pg & 1]);
+                if constexpr (ka == N4 - 1) {
+                    if (st_ok && 4 * pg + z < M && (!(QS_QUAD4S_ABLATE & 2) || o2[pg & 1] == 12345.678))
+                        orow[(int64_t)(4 * pg) * g.out_row] = o2[pg & 1];
+                }
+            }
             __builtin_amdgcn_sched_barrier(0);
-        });
-        // ---- store.  D: row z, block y = item, column x.
-        const unsigned it_g = unit * 4 + y;
-        double* orow = g.out + (int64_t)it_g * g.out_item + z * g.out_row + x * g.out_col;
-        const int col = 4 * jg + x;
-        unroll_q<0, N4>([&](auto PG) __attribute__((always_inline)) {
-            constexpr int pg = decltype(PG)::value;
-            if (it_g < g.nitems && 4 * pg + z < M && col < M)
-                orow[(int64_t)(4 * pg) * g.out_row + (int64_t)(4 * jg) * g.out_col] = o[pg];
-            __builtin_amdgcn_sched_barrier(0);              // (or all N4 addresses are formed up front: registers)
         });
         // ---- the next quad: its descriptor and offsets, the fetch registers back in step (pf[i] = row quad 1 + i)
         rs_cur = rs_nx;
@@ -236,11 +253,16 @@ __global__ __launch_bounds__(64 * N4) void quad4s_kernel(const Quad4Args g) {
             unroll_q<0, P>([&](auto I) __attribute__((always_inline)) { t_[decltype(I)::value] = pf[(N4 + decltype(I)::value) % P]; });
             unroll_q<0, P>([&](auto I) __attribute__((always_inline)) { pf[decltype(I)::value] = t_[decltype(I)::value]; });
         }
-        if constexpr (N4 & 1) {                             // the next quad's first row quad sits in the other slot
-            int tmp;
-            tmp = a_of[0]; a_of[0] = a_of[1]; a_of[1] = tmp;
-            tmp = w0_of[0]; w0_of[0] = w0_of[1]; w0_of[1] = tmp;
-            tmp = w1_of[0]; w1_of[0] = w1_of[1]; w1_of[1] = tmp;
+        if constexpr (N4 % NR != 0) {                       // the next quad's first row quad sits in slot N4 % NR of this numbering
+            int ta[NR], t0[NR], t1[NR];
+            unroll_q<0, NR>([&](auto I) __attribute__((always_inline)) {
+                constexpr int i = decltype(I)::value;
+                ta[i] = a_of[(i + N4) % NR]; t0[i] = w0_of[(i + N4) % NR]; t1[i] = w1_of[(i + N4) % NR];
+            });
+            unroll_q<0, NR>([&](auto I) __attribute__((always_inline)) {
+                constexpr int i = decltype(I)::value;
+                a_of[i] = ta[i]; w0_of[i] = t0[i]; w1_of[i] = t1[i];
+            });
         }
     }
 }
@@ -248,7 +270,7 @@ __global__ __launch_bounds__(64 * N4) void quad4s_kernel(const Quad4Args g) {
 template <int N4>
 static int launch_quad4s(const Quad4Args& g, hipStream_t stream) {
     constexpr int K4 = 4 * N4, Lp = (K4 % 8 == 4) ? K4 : K4 + 4;
-    constexpr size_t lds = sizeof(double) * (2 * 2 * (2 * 4 * Lp + 2) + N4 * N4 * 16);
+    constexpr size_t lds = sizeof(double) * (3 * 2 * (2 * 4 * Lp + 2) + N4 * N4 * 16);
     // every byte offset inside an item quad stays below 2^31 (32-bit lane and scalar offsets of the fetch)
     const int64_t span = (3 * (int64_t)g.in_item + (int64_t)K4 * (g.in_row > g.in_col ? g.in_row : g.in_col) * 2) * 8 + 16;
     if (span >= (int64_t(1) << 31)) return 1;
