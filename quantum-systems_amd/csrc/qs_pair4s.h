@@ -109,13 +109,14 @@ __global__ __launch_bounds__(64 * stream_waves(N4)) void pair4s_kernel(const Pai
     constexpr int ITEM = 4 * Lp;                 // == 16 mod 32 doubles (Lp == 4 mod 8)
     constexpr int PLANE = 2 * ITEM + 2;          // == 2 mod 32
     constexpr int SLOT = 2 * PLANE;
+    constexpr int NR = NJ == 1 ? 3 : 2;          // ring slots: three for the two-phase form (one group per wave), see its barrier
     constexpr int TABLE = N4 * N4 * 16;
     constexpr int P = N4 > 3 ? 3 : N4 - 1;       // row quads in flight between their fetch and the ring
     static_assert(8 * K4 <= NTH, "one element per thread and row quad");
     static_assert(P < N4, "a fetch reaches into the next pair at most");
     extern __shared__ __attribute__((aligned(16))) double lds[];
     double* ring = lds;                          // [2 slots][re, im][2 items][4 rows][Lp]
-    double* ltab = lds + 2 * SLOT;               // [re, im][pg][ka][16]: Lm[4 pg + x][4 ka + z] at z * 4 + x
+    double* ltab = lds + NR * SLOT;              // [re, im][pg][ka][16]: Lm[4 pg + x][4 ka + z] at z * 4 + x
     const int L = g.L, M = g.M;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -175,12 +176,12 @@ __global__ __launch_bounds__(64 * stream_waves(N4)) void pair4s_kernel(const Pai
             else { ring[w] = v.x; ring[w + PLANE] = v.y; }
         }
     };
-    // ring slot of row quad ka of the CURRENT unit: (ka & 1) ^ flip (the parity of a pair's first row quad alternates
-    // from pair to pair when N4 is odd); kept as two bases each, exchanged at the end of such a unit
+    // ring slot of row quad ka of the CURRENT unit: index ka % NR into these bases, which are rotated by N4 % NR at the end of
+    // a unit (the next pair's first row quad follows this one's last)
     const int a_base = item * ITEM + x * Lp + z;
-    int a1_of[2], a2_of[2], w_of[2];
+    int a1_of[NR], a2_of[NR], w_of[NR];
 #pragma unroll
-    for (int sl = 0; sl < 2; ++sl) {
+    for (int sl = 0; sl < NR; ++sl) {
         a1_of[sl] = sl * SLOT + a_base + ((tb && part) ? PLANE : 0);     // In_re; (b contraction) In_re / In_im by part
         a2_of[sl] = sl * SLOT + a_base + ((tb && part) ? 0 : PLANE);     // In_im; (b contraction) In_im / In_re by part
         w_of[sl] = sl * SLOT + f_pos;
@@ -238,6 +239,79 @@ __global__ __launch_bounds__(64 * stream_waves(N4)) void pair4s_kernel(const Pai
     __syncthreads();
 
     for (; unit < u_end; unit += slots) {
+      if constexpr (NJ == 1) {
+        // TWO PHASES per item pair (one column group per wave): Y[ka] = In[ka] . R[:, group] for every row quad ka -- Y and its
+        // exchanged copy stay in registers, already in B-operand layout -- then Out[pg] = sum_ka Lm[pg][ka] . Y[ka] for every
+        // row quad pg, a finished row quad of Out leaving during the next one's MFMAs.  (Both products per ka, as in the
+        // two-groups form below, hold all of Out to the end of the unit: every workgroup of the chip then stores a whole pair
+        // at once -- in the fp64 sibling those stores were 23-38 % of the launch, profiles/r03_quad4s.txt.)
+        double Y[N4], Ys[N4];
+        double o2[2];
+        constexpr int NG = N4 * N4;
+        auto operands = [&](auto T, double& p0, double& p1) __attribute__((always_inline)) {
+            constexpr int t = decltype(T)::value;
+            if constexpr (t < NG) {
+                p0 = ring[a1_of[(t / N4) % NR] + 4 * (t % N4)];
+                if constexpr (!REAL_IN) p1 = ring[a2_of[(t / N4) % NR] + 4 * (t % N4)];
+            } else {
+                p0 = ltab[(t - NG) * 16 + e_lane];                      // Lm[pg][ka], (pg, ka) = t - NG
+                p1 = ltab[TABLE + (t - NG) * 16 + e_lane];
+            }
+        };
+        constexpr int AHEAD = N4 > 2 ? 2 : 1;               // groups between the read of the operands and their MFMAs
+        static_assert(AHEAD < N4, "the read-ahead into the next row quad's slot starts behind the step's barrier");
+        double opr[AHEAD + 1][2];
+        unroll<0, AHEAD>([&](auto T) __attribute__((always_inline)) {
+            constexpr int t = decltype(T)::value;
+            operands(T, opr[t % (AHEAD + 1)][0], opr[t % (AHEAD + 1)][1]);
+        });
+        const unsigned it_g = unit * 2 + item;              // D: row z, block (item, part), column x
+        double* orow = g.out + ((int64_t)it_g * g.out_item + z * g.out_row + x * g.out_col + (int64_t)(4 * jg0) * g.out_col) * 2 + part;
+        const bool st_ok = it_g < g.nitems && 4 * jg0 + x < M;
+        unroll<0, 2 * NG>([&](auto T) __attribute__((always_inline)) {
+            constexpr int t = decltype(T)::value, sl = t % (AHEAD + 1);
+            if constexpr (t < NG && t % N4 == 0) {
+                // step start: row quad ka + 1 (the next pair's first after the last step) leaves its registers for its slot,
+                // the fetch of row quad ka + 1 + P takes its place
+                constexpr int ka = t / N4;
+                settle(w_of[(ka + 1) % NR], pf[ka % P]);
+                constexpr int tq = ka + 1 + P;
+                if constexpr (tq < N4) pf[ka % P] = fetch(rs_cur, v_cur, std::integral_constant<int, tq>{});
+                else pf[ka % P] = fetch(rs_nx, v_nx, std::integral_constant<int, tq - N4>{});
+            }
+            if constexpr (t < NG && t % N4 == 1) {
+                // The step's barrier, right behind its write.  The slot written at the start of step ka holds row quad ka + 1:
+                // it is first read -- by the operand read-ahead, from group N4 - AHEAD >= 1 of this step on -- behind this
+                // barrier; and it was last read in step ka - 2, which every wave had finished when it arrived at the barrier
+                // of step ka - 1 (three slots: with two, a wave still in step ka - 1 would be reading it).  It waits for the
+                // wave's LDS traffic only: the fetches stay in flight.
+                __builtin_amdgcn_s_waitcnt(0xC07F);         // lgkmcnt(0), vmcnt / expcnt untouched
+                __builtin_amdgcn_s_barrier();
+            }
+            if constexpr (t + AHEAD < 2 * NG)
+                operands(std::integral_constant<int, t + AHEAD>{}, opr[(t + AHEAD) % (AHEAD + 1)][0], opr[(t + AHEAD) % (AHEAD + 1)][1]);
+            const double cur0 = opr[sl][0], cur1 = opr[sl][1];
+            if constexpr (t < NG) {                         // Y[ka] += In[ka][ks] . R[ks]
+                constexpr int ka = t / N4, ks = t % N4;
+                Y[ka] = mfma4(cur0, b1[ks][0], ks == 0 ? 0.0 : Y[ka]);
+                if constexpr (!REAL_IN) Y[ka] = mfma4(cur1, b2[ks][0], Y[ka]);
+                if constexpr (ks == N4 - 1) {
+                    // second operand of Lm_im: the other part of the same item, the block that feeds the real part negated
+                    const double other = other_part(Y[ka]);
+                    Ys[ka] = part ? other : -other;
+                }
+            } else {                                        // Out[pg] += Lm[pg][ka] . Y[ka]
+                constexpr int pg = (t - NG) / N4, ka = (t - NG) % N4;
+                o2[pg & 1] = mfma4(cur0, Y[ka], ka == 0 ? 0.0 : o2[pg & 1]);
+                o2[pg & 1] = mfma4(cur1, Ys[ka], o2[pg & 1]);
+                if constexpr (ka == N4 - 1) {
+                    if (st_ok && 4 * pg + z < M && (!(QS_PAIR4C_ABLATE & 2) || o2[pg & 1] == 12345.678))
+                        orow[(int64_t)(4 * pg) * g.out_row * 2] = o2[pg & 1];
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        });
+      } else {
         double o[N4][NJ];
         double yv[NJ], ys[NJ];
         constexpr int GPK = 2 * N4;                         // groups per row quad of Y: N4 of the first product, N4 of the second
@@ -324,6 +398,7 @@ __global__ __launch_bounds__(64 * stream_waves(N4)) void pair4s_kernel(const Pai
             });
             __builtin_amdgcn_sched_barrier(0);
         });
+      }
         // ---- the next pair: its descriptor and offsets, the fetch registers back in step (pf[i] = row quad 1 + i)
         rs_cur = rs_nx;
         v_cur[0] = v_nx[0]; v_cur[1] = v_nx[1];
@@ -334,11 +409,16 @@ __global__ __launch_bounds__(64 * stream_waves(N4)) void pair4s_kernel(const Pai
             unroll<0, P>([&](auto I) __attribute__((always_inline)) { t_[decltype(I)::value] = pf[(N4 + decltype(I)::value) % P]; });
             unroll<0, P>([&](auto I) __attribute__((always_inline)) { pf[decltype(I)::value] = t_[decltype(I)::value]; });
         }
-        if constexpr (N4 & 1) {                             // the next pair's first row quad sits in the other slot
-            int tmp;
-            tmp = a1_of[0]; a1_of[0] = a1_of[1]; a1_of[1] = tmp;
-            tmp = a2_of[0]; a2_of[0] = a2_of[1]; a2_of[1] = tmp;
-            tmp = w_of[0]; w_of[0] = w_of[1]; w_of[1] = tmp;
+        if constexpr (N4 % NR != 0) {                       // the next pair's first row quad sits in slot N4 % NR of this numbering
+            int t1[NR], t2[NR], tw[NR];
+            unroll<0, NR>([&](auto I) __attribute__((always_inline)) {
+                constexpr int i = decltype(I)::value;
+                t1[i] = a1_of[(i + N4) % NR]; t2[i] = a2_of[(i + N4) % NR]; tw[i] = w_of[(i + N4) % NR];
+            });
+            unroll<0, NR>([&](auto I) __attribute__((always_inline)) {
+                constexpr int i = decltype(I)::value;
+                a1_of[i] = t1[i]; a2_of[i] = t2[i]; w_of[i] = tw[i];
+            });
         }
     }
 }
@@ -346,7 +426,7 @@ __global__ __launch_bounds__(64 * stream_waves(N4)) void pair4s_kernel(const Pai
 template <int N4, bool REAL_IN = false>
 int launch_pair4s(const Pair4Args& g, hipStream_t stream) {
     constexpr int K4 = 4 * N4, Lp = (K4 % 8 == 4) ? K4 : K4 + 4;
-    constexpr size_t lds = sizeof(double) * (2 * 2 * (2 * 4 * Lp + 2) + 2 * N4 * N4 * 16);
+    constexpr size_t lds = sizeof(double) * ((stream_groups(N4) == 1 ? 3 : 2) * 2 * (2 * 4 * Lp + 2) + 2 * N4 * N4 * 16);
     static PerDeviceLds lds_opt_in;
     if (int rc = opt_in_dynamic_lds((const void*)pair4s_kernel<N4, REAL_IN>, lds, lds_opt_in, "hipFuncSetAttribute(pair4s)")) return rc;
     const int n_cu = device_cu_count();
