@@ -73,7 +73,13 @@ __global__ __launch_bounds__(64 * N4) void quad4s_kernel(const Quad4Args g) {
     constexpr int SLOT = 2 * PLANE;
     constexpr int NR = 3;                        // ring slots (see the hazard note at the step barrier)
     constexpr int TABLE = N4 * N4 * 16;
-    constexpr int P = N4 > 3 ? 3 : N4 - 1;       // row quads in flight between their fetch and the ring
+#ifndef QS_QUAD4S_P
+#define QS_QUAD4S_P 3
+#endif
+#ifndef QS_QUAD4S_AHEAD
+#define QS_QUAD4S_AHEAD 3
+#endif
+    constexpr int P = N4 > QS_QUAD4S_P ? QS_QUAD4S_P : N4 - 1;       // row quads in flight between their fetch and the ring
     static_assert(8 * K4 <= NTH, "one 16-byte element pair per thread and row quad");
     static_assert(P < N4, "a fetch reaches into the next quad at most");
     extern __shared__ __attribute__((aligned(16))) double lds[];
@@ -200,7 +206,7 @@ __global__ __launch_bounds__(64 * N4) void quad4s_kernel(const Quad4Args g) {
             if constexpr (t < NG) return ring[a_of[(t / N4) % NR] + 4 * (t % N4)];                 // In[ka][ks]
             else return ltab[(t - NG) * 16 + e_lane];                                              // Lm[pg][ka], (pg, ka) = t - NG
         };
-        constexpr int AHEAD = N4 > 3 ? 3 : N4 - 1;          // groups between the read of an operand and its MFMA
+        constexpr int AHEAD = N4 > QS_QUAD4S_AHEAD ? QS_QUAD4S_AHEAD : N4 - 1;          // groups between the read of an operand and its MFMA
         static_assert(AHEAD < N4, "the read-ahead into the next row quad's slot starts behind the step's barrier");
         double opr[AHEAD + 1];
         unroll_q<0, AHEAD>([&](auto T) __attribute__((always_inline)) { opr[decltype(T)::value % (AHEAD + 1)] = operand(T); });
