@@ -437,7 +437,7 @@ int launch_pair4s(const Pair4Args& g, hipStream_t stream) {
     const int64_t span = ((int64_t)g.in_item + (int64_t)K4 * (g.in_row > g.in_col ? g.in_row : g.in_col) * 2) * 16;
     if (span >= (int64_t(1) << 31)) return 1;
     hipLaunchKernelGGL((pair4s_kernel<N4, REAL_IN>), dim3(wgs), dim3(64 * stream_waves(N4)), lds, stream, g);
-    note_dispatch(REAL_IN ? "qs::pair4s_kernel<%d, true>" : "qs::pair4s_kernel<%d>", N4);
+    note_dispatch(REAL_IN ? "qs::pair4s_kernel<%d, true>" : "qs::pair4s_kernel<%d, false>", N4);     // (the symbol's name in a profile)
     return launch_status("pair4s launch");
 }
 

@@ -76,7 +76,7 @@ def test_mixed_real_u_complex_C_runs_without_a_complex_copy_of_u(K, golden):
     got = K.transform_two_body(u, C)
     ran = K.last_dispatch().split(";")
     if "pair4s" in ran[0]:           # small bases: the streamed fused kernel with REAL items for the first pass
-        assert ran[0].endswith(", true>") and "pair4s" in ran[1] and "true" not in ran[1], ran
+        assert ran[0].endswith(", true>") and "pair4s" in ran[1] and ran[1].endswith(", false>"), ran
         with K.tuning(pair4c=0):     # ... bit-identical to the tiled route (real product for d, then complex)
             tiled = K.transform_two_body(u, C)
             assert "pair4s" not in K.last_dispatch()
@@ -227,7 +227,7 @@ def test_complex_fused_kernel_is_bit_identical_to_the_16_wide_path(K):
         Ct = dev((rng.standard_normal((M, L)) + 1j * rng.standard_normal((M, L))) / np.sqrt(L))
         with K.tuning(pair4c=2, small4=0):
             got = K.transform_two_body(u, C, Ct)
-            assert K.last_dispatch() == f"qs::pair4s_kernel<{-(-L // 4)}> x2", (L, M, K.last_dispatch())
+            assert K.last_dispatch() == f"qs::pair4s_kernel<{-(-L // 4)}, false> x2", (L, M, K.last_dispatch())
         K.transform_two_body(u, C, Ct)
         assert ("pair4s" in K.last_dispatch()) == (max(L, M) <= 56), (L, M, K.last_dispatch())
         with K.tuning(pair4c=0, small4=0):

@@ -22,6 +22,13 @@ line() {   # name, bench args...
 line bench_l256_f64 --steps 10 --warmup 2
 line bench_l55_f64 --orbitals 55 --steps 200 --warmup 20
 line bench_l56_f64 --orbitals 56 --steps 200 --warmup 20 --no-cpu-baseline
+line bench_l55_c128 --orbitals 55 --dtype c128 --steps 100 --warmup 10 --no-cpu-baseline
 line bench_l48_c128 --orbitals 48 --dtype c128 --steps 100 --warmup 10 --no-cpu-baseline
 line bench_l36_c128 --orbitals 36 --dtype c128 --steps 200 --warmup 20 --no-cpu-baseline
+line bench_l20_c128 --orbitals 20 --dtype c128 --steps 400 --warmup 40 --no-cpu-baseline
+line bench_l20_f64 --orbitals 20 --steps 400 --warmup 40 --no-cpu-baseline
+line bench_l32_f64 --orbitals 32 --steps 400 --warmup 40 --no-cpu-baseline
+line bench_l55_mixed --orbitals 55 --dtype mixed --steps 100 --warmup 10 --no-cpu-baseline
 line bench_l128_f64 --orbitals 128 --steps 30 --warmup 3 --no-cpu-baseline
+echo "== api overhead"
+timeout -k 10 300 python tools/api_overhead.py 2>&1 | grep -v amdgpu.ids | tee $OUT/api_overhead.txt
