@@ -407,7 +407,17 @@ const char* qs_last_dispatch(void);
  *     1 four adjacent quads per workgroup, 3 the same with a barrier per step),
  *     "sandwich_t2" (the intermediate between those passes stored transposed,
  *     (r, s, a, b), so that the second pass fetches slabs too: -1 automatic,
- *     0 never, 1 always).
+ *     0 never, 1 always), "sandwich_v2" (the balanced form of those passes:
+ *     -1 automatic, 0 never, 1 wherever it exists, 2 also odd quad counts on
+ *     the next even instantiation), "sandwich_tail" (0 = never split the item
+ *     quads of a partly filled last round over all workgroups), "small4"
+ *     (the whole-quad kernel of up to 32 orbitals: 0 never, 1 automatic,
+ *     2 wherever it exists), "quad4s" (the streamed fp64 kernel of 5-64
+ *     orbitals: 0 never, 1 automatic, 2 wherever it exists), "pair4c" (the
+ *     streamed complex128 / real-tensor-complex-coefficients kernel of 5-64
+ *     orbitals: 0 never, 1 automatic, 2 wherever it exists), "gemm_fit"
+ *     (fitted tile shapes of the general kernel: 0 never, 1 automatic, 2 always),
+ *     "gemm_pick" (0 = tile shape by padded area only).
  *   qs_probe_mfma_f64: register-resident fp64 MFMA loop, `blocks` workgroups
  *     of 4 waves, each wave issuing iters*8 v_mfma_f64_16x16x4_f64
  *     (flops = blocks*4*iters*8*2048); `sink` is a device scratch of
