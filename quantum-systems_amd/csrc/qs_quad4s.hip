@@ -140,8 +140,10 @@ __global__ __launch_bounds__(64 * N4) void quad4s_kernel(const Quad4Args g) {
     };
     auto settle = [&](int w0, int w1, f64x2q v, bool shifted) __attribute__((always_inline)) {
         if (loader) {
-            ring[w0] = shifted ? v.y : v.x;
-            ring[w1] = shifted ? 0.0 : v.y;
+            const f64x2q pr = shifted ? f64x2q{v.y, 0.0} : v;
+            // (slabs: the two elements are neighbours in the slot -- w0 is even, Lp, ITEM, PLANE and SLOT are -- one 16-byte write)
+            if (slab) *reinterpret_cast<f64x2q*>(ring + w0) = pr;
+            else { ring[w0] = pr.x; ring[w1] = pr.y; }
         }
     };
     // ring slot of row quad ka of the CURRENT quad: index ka % NR into these bases, which are rotated by N4 % NR at the end
