@@ -287,7 +287,10 @@ static int launch_quad4s(const Quad4Args& g, hipStream_t stream) {
     const int n_cu = device_cu_count();
     unsigned wgs = (g.nquads + 7u) / 8u * 8u;
     // workgroups resident per CU: by threads (2048 per CU) and LDS
-    const unsigned per_cu = (64 * N4 <= 512 && lds <= 80 * 1024) ? 2u : 1u;
+#ifndef QS_QUAD4S_TWO_PER_CU_TO
+#define QS_QUAD4S_TWO_PER_CU_TO 8
+#endif
+    const unsigned per_cu = (N4 <= QS_QUAD4S_TWO_PER_CU_TO && lds <= 80 * 1024) ? 2u : 1u;
     const unsigned cap = per_cu * (unsigned)(n_cu - n_cu % 8 > 8 ? n_cu - n_cu % 8 : 8);
     if (wgs > cap) wgs = cap;
     hipLaunchKernelGGL((quad4s_kernel<N4>), dim3(wgs), dim3(64 * N4), lds, stream, g);
