@@ -272,7 +272,12 @@ namespace qs {
 // where the streamed fp64 kernel measured faster than the other small-basis paths (profiles/r03_quad4s.txt)
 // (9 ... 16 orbitals: 1.06-1.14x over qs_small4.hip; 17 ... 32: 1.12-1.21x over it / the 16-wide kernels, l = 20 10.2 -> 9.1 us, 32 22.4 -> 19.8; from 33
 // the hand-scheduled qs_sandwich4*.hip stay ahead, 0.72-0.86x)
-static bool quad4s_wins(int64_t L, int64_t M) { return L >= 9 && M >= 9 && L <= 32 && M <= 32; }
+// 65 ... 95 orbitals (two workgroups per item quad): 1.05-1.42x over the tiled kernels, every size (l = 66 444 -> 331 us, 78 740 -> 585,
+// 91 1406 -> 1113); 96 itself level (0.98x): the tiled kernels keep it.
+static bool quad4s_wins(int64_t L, int64_t M) {
+    if (L >= 9 && M >= 9 && L <= 32 && M <= 32) return true;
+    return L >= 65 && M >= 65 && L <= 96 && M <= 96 && !(L == 96 && M == 96);
+}
 
 static int transform_two_body_impl(int in_dtype, int dtype, const void* u, const void* C, const void* Ct, void* out,
                                    void* work, int64_t work_bytes, int64_t L, int64_t M, void* stream) {
@@ -309,9 +314,9 @@ static int transform_two_body_impl(int in_dtype, int dtype, const void* u, const
         if (rc1 != 1) return rc1;
     }
 
-    // fp64, 17 ... 64 orbitals: the two passes on the streamed kernel (qs_quad4s.hip) where it measured faster than what
+    // fp64, 5 ... 96 orbitals: the two passes on the streamed kernel (qs_quad4s.h) where it measured faster than what
     // follows (profiles/r03_quad4s.txt).  g_tune.quad4s == 2: wherever it exists.
-    if (in_dtype == dtype && dtype == QS_F64 && g_tune.quad4s && L >= 5 && M >= 5 && L <= 64 && M <= 64 && n4s == cdiv(M, 4) &&
+    if (in_dtype == dtype && dtype == QS_F64 && g_tune.quad4s && L >= 5 && M >= 5 && L <= 96 && M <= 96 && n4s == cdiv(M, 4) &&
         (g_tune.quad4s == 2 || (quad4s_wins(L, M) && g_tune.sandwich < 4))) {       // (sandwich >= 4: tuning runs of those kernels)
         const int64_t MM = M * M;
         int rc1 = quad4s_try(dtype, u, WA, C, M, 1, C, 1, M, L * L, L, M, L * L, L, 1, MM, M, 1, s);

@@ -190,19 +190,22 @@ def test_streamed_fp64_kernel_is_bit_identical_to_the_16_wide_path(K):
     shapes = [(l, l) for l in (5, 8, 9, 11, 12, 13, 16, 17, 19, 20, 21, 24, 25, 27, 28, 29, 31, 32, 33, 36, 39, 41, 45, 48, 50, 53,
                                55, 56, 57, 60, 63, 64)]
     shapes += [(7, 5), (10, 12), (18, 20), (20, 17), (30, 32), (32, 29), (55, 53), (62, 64)]     # rectangular within one quad count
+    shapes += [(65, 65), (66, 68), (71, 69), (77, 78), (84, 81), (91, 91), (96, 93)]             # two workgroups per item quad
     for (L, M) in shapes:
         u = dev(rng.standard_normal((L,) * 4))
         C = dev(rng.standard_normal((L, M)) / np.sqrt(L))
         Ct = dev(rng.standard_normal((M, L)) / np.sqrt(L))
         with K.tuning(quad4s=2, small4=0):
             got = K.transform_two_body(u, C, Ct)
-            assert K.last_dispatch() == f"qs::quad4s_kernel<{-(-L // 4)}> x2", (L, M, K.last_dispatch())
+            name = f"qs::quad4s_kernel<{-(-L // 4)}{', 2' if L > 64 else ''}>"
+            assert K.last_dispatch() == f"{name} x2", (L, M, K.last_dispatch())
         with K.tuning(quad4s=0, small4=0, sandwich=0):
             wide = K.transform_two_body(u, C, Ct)
             assert "quad4s" not in K.last_dispatch() and "sandwich4" not in K.last_dispatch() and "small4" not in K.last_dispatch()
         assert torch.equal(got, wide), (L, M)
         K.transform_two_body(u, C, Ct)
-        assert ("quad4s" in K.last_dispatch()) == (9 <= min(L, M) and max(L, M) <= 32), (L, M, K.last_dispatch())
+        auto = (9 <= min(L, M) and max(L, M) <= 32) or (65 <= min(L, M) and (L, M) != (96, 96))
+        assert ("quad4s" in K.last_dispatch()) == auto, (L, M, K.last_dispatch())
     # an item count that is not a multiple of four next to poisoned memory, and non-finite values staying in their slabs
     L = 21
     big = torch.full((L + 1, L, L, L), float("nan"), dtype=torch.float64, device="cuda")

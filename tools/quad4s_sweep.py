@@ -49,7 +49,7 @@ for l in sizes:
     C = torch.linalg.qr(C)[0].contiguous()
     Ct = C.T.contiguous()
     out = torch.empty_like(u)
-    reps = 40 if l <= 32 else 10
+    reps = 40 if l <= 32 else 10 if l <= 64 else 4
     K.tuning_set("quad4s", 2)
     K.tuning_set("small4", 0)
     a = K.transform_two_body(u, C, Ct).clone()
