@@ -30,7 +30,10 @@ over its leading index p.  Layouts:
               rows of the other out, streamed (input rows + result rows + O(l^3) per GPU),
               one all-to-all per chunk of rows through torch.distributed;
   rows_rccl   the same as ONE C-ABI call (qs_transform_two_body_sharded_rows), the exchange
-              on the communicator's stream under the next chunk's products.
+              on the communicator's stream under the next chunk's products: one message per
+              (peer, result row), landing in place;
+  rows_rccl_coalesced   the same call with ONE message per peer and step (the handle's option
+              "rows_coalesce": staging area + one strided copy on the communicator's stream).
 The north star's single all-gather (replicating the p-sharded result) is timed
 as a second leg and reported next to the no-collective value; `--gather` makes
 it part of `value`.
@@ -38,7 +41,10 @@ it part of `value`.
 `--layout auto` at N > 1 (what the driver's one command runs) measures EVERY layout that
 fits, one after the other, each as its own group of fresh rank processes (a leg that fails or
 hangs is recorded and killed, the others stand): `legs` holds each leg's TFLOP/s, ms/step and
-parity; `value` is the best leg whose time INCLUDES a collective (replicated + all-gather of
+parity.  After EVERY leg rank 0 prints a complete line composed from the legs measured so far
+(`"provisional": true`); the final line comes last.  A leg is killed after --leg-timeout
+seconds and nothing runs past --total-budget, so a hanging leg can neither take the measured
+legs with it nor push the run over the driver's limit.  `value` is the best leg whose time INCLUDES a collective (replicated + all-gather of
 the result, or a sharded layout with its all-to-all), and `config.layout` names it.
 `--config 3` = BASELINE.json configs[3] (spin expansion l=256 -> 512), `--config 4` =
 configs[4] (l=512 complex128, slabs generated per rank, rows layout, a new C(t) per step;
@@ -76,14 +82,19 @@ def parse(argv=None):
     ap.add_argument("--mixed-route", choices=["native", "cast"], default="native",
                     help="native: the real tensor is read as it is (qs_transform_two_body_mixed); cast: rounds 1-2, a "
                          "complex copy of the tensor first (A/B)")
-    ap.add_argument("--layout", choices=["auto", "replicated", "sharded", "inplace", "rccl", "rows", "rows_rccl"],
-                    default="auto")
+    ap.add_argument("--layout", choices=["auto", "replicated", "sharded", "inplace", "rccl", "rows", "rows_rccl",
+                                         "rows_rccl_coalesced"], default="auto")
     ap.add_argument("--config", type=int, choices=[2, 3, 4], default=None,
                     help="preset: BASELINE.json configs[2] (default), [3] spin expansion l=256 -> 512, "
                          "[4] l=512 complex128 time-evolution pattern on per-rank slabs")
-    ap.add_argument("--legs", default="replicated,rows,rows_rccl,rccl",
-                    help="layouts measured by --layout auto at N > 1, in this order")
-    ap.add_argument("--leg-timeout", type=float, default=300.0, help="seconds before a leg is given up and killed")
+    ap.add_argument("--legs", default="replicated,rows,rows_rccl,rows_rccl_coalesced,rccl",
+                    help="layouts measured by --layout auto at N > 1, in this order (the torch.distributed legs first: the "
+                         "legs that drive RCCL directly have never run on more than one rank before the driver's node)")
+    ap.add_argument("--leg-timeout", type=float, default=100.0,
+                    help="seconds before a leg is given up and killed (the first leg gets twice that)")
+    ap.add_argument("--total-budget", type=float, default=520.0,
+                    help="seconds from the start of this process after which no leg is started or kept alive: the line of "
+                         "the legs measured so far stands (the driver gives a run 600 s)")
     ap.add_argument("--chunk-rows", type=int, default=0, help="input rows per exchange step of the rows layouts (0 = automatic)")
     ap.add_argument("--gather", action="store_true", help="make the all-gather of the result part of `value`")
     ap.add_argument("--no-gather-leg", action="store_true", help="skip the second, gather-inclusive timing leg at N > 1")
@@ -181,34 +192,55 @@ def _without_option(argv, name, has_value=True):
     return out
 
 
+T_START = time.monotonic()
+
+
+def warm_import(timeout):
+    """Page the image's torch in (1-2 minutes on a fresh box, seconds afterwards) in a child of its own, so that the first
+    leg's clock measures the leg.  Never touches the GPU."""
+    try:
+        subprocess.run([sys.executable, "-c", "import torch, numpy"], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL,
+                       timeout=timeout)
+    except (subprocess.TimeoutExpired, OSError):
+        pass
+
+
 def run_legs(args, n, under_launcher):
     """`--layout auto` at N > 1: every layout of `--legs` measured as its OWN group of fresh rank processes, one after
-    the other; rank 0 composes ONE line.  Without an external launcher this process starts each group itself
-    (`launch_group`).  Under `torch.distributed.run` this process IS rank RANK of the driver's launch: it then starts
-    one child per leg -- its rank of that leg's own process group (own rendezvous port) -- and never touches the GPU
-    itself, so a leg whose communicator code fails or hangs (the RCCL entry points of the C ABI have never run on
-    more than one rank before the driver's node) costs that leg only: the child is killed at `--leg-timeout`, the leg
-    is recorded as failed and the line still carries every other leg."""
+    the other; rank 0 composes ONE line -- and prints a provisional one after every leg.  Without an external launcher
+    this process starts each group itself (`launch_group`).  Under `torch.distributed.run` this process IS rank RANK of
+    the driver's launch: it then starts one child per leg -- its rank of that leg's own process group (own rendezvous
+    port) -- and never touches the GPU itself, so a leg whose communicator code fails or hangs (the RCCL entry points of
+    the C ABI have never run on more than one rank before the driver's node) costs that leg only: the child is killed at
+    `--leg-timeout`, the leg is recorded as failed and the line still carries every other leg.  No leg is started, or
+    kept alive, past `--total-budget` seconds after the start of this process."""
     legs = [x for x in args.legs.split(",") if x]
     argv = _without_option(sys.argv[1:], "--layout")
     rank = int(os.environ.get("RANK", "0")) if under_launcher else 0
+    deadline = T_START + args.total_budget
+    warm_import(min(240.0, max(10.0, deadline - time.monotonic() - 60.0)))
     records = {}
+    rc_all = 1
     for k, leg in enumerate(legs):
         leg_argv = argv + ["--layout", leg]
         t0 = time.monotonic()
+        limit = min(args.leg_timeout * (2 if k == 0 else 1), deadline - t0 - 2.0)
+        if limit < 15.0:
+            records[leg] = {"status": "skipped (out of time: --total-budget)", "wall_s": 0.0}
+            continue
         if under_launcher:
             env = {kk: v for kk, v in os.environ.items() if not kk.startswith("TORCHELASTIC")}
             env["MASTER_PORT"] = str(int(os.environ.get("MASTER_PORT", "29500")) + 1 + k)
             env["QS_BENCH_LEG"] = leg
             try:
                 res = subprocess.run([sys.executable, os.path.abspath(__file__)] + leg_argv, env=env,
-                                     stdout=subprocess.PIPE, stderr=sys.stderr, text=True, timeout=args.leg_timeout)
+                                     stdout=subprocess.PIPE, stderr=sys.stderr, text=True, timeout=limit)
                 rc, lines = res.returncode, res.stdout.splitlines()
             except subprocess.TimeoutExpired as exc:          # (run() has killed and reaped the child)
                 rc, lines = 124, (exc.stdout or "").splitlines() if isinstance(exc.stdout, str) else []
         else:
-            rc, lines = launch_group(n, leg_argv, timeout=args.leg_timeout, extra_env={"QS_BENCH_LEG": leg})
-        rec = {"status": "ok" if rc == 0 else f"failed (exit code {rc}{', timed out' if rc == 124 else ''})",
+            rc, lines = launch_group(n, leg_argv, timeout=limit, extra_env={"QS_BENCH_LEG": leg})
+        rec = {"status": "ok" if rc == 0 else f"failed (exit code {rc}{', timed out after %.0f s' % limit if rc == 124 else ''})",
                "wall_s": time.monotonic() - t0}
         for ln in lines:
             if ln.lstrip().startswith("{"):
@@ -219,14 +251,22 @@ def run_legs(args, n, under_launcher):
         if rc == 0 and "line" not in rec and rank == 0:
             rec["status"] = "failed (no result line)"
         records[leg] = rec
+        if rank == 0:
+            # a COMPLETE line after every leg: whatever happens to the legs still to come, the last line on stdout
+            # carries everything measured so far (the final one, without the flag, comes last)
+            done = [x for x in legs if x in records]
+            rc_all = compose_legs(args, n, done, records, provisional=k + 1 < len(legs), pending=legs[k + 1:])
     if rank != 0:
         return 0
-    return compose_legs(args, n, legs, records)
+    if legs and legs[-1] in records and records[legs[-1]]["status"].startswith("skipped"):
+        rc_all = compose_legs(args, n, [x for x in legs if x in records], records, provisional=False, pending=[])
+    return rc_all
 
 
-def compose_legs(args, n, legs, records):
+def compose_legs(args, n, legs, records, provisional=False, pending=()):
     """ONE line from the legs: `value` = the best leg whose time includes a collective."""
     summary, candidates = {}, []
+    extra = {"provisional": True, "legs_pending": list(pending)} if provisional else {}
     for leg in legs:
         rec = records[leg]
         d = rec.get("line")
@@ -244,16 +284,17 @@ def compose_legs(args, n, legs, records):
                 candidates.append((d["value"], leg, d, None))
         summary[leg] = ent
     if not candidates:
-        print("bench.py: no leg with a collective in its time finished", file=sys.stderr)
+        if not provisional:
+            print("bench.py: no leg with a collective in its time finished", file=sys.stderr)
         fallback = [records[leg].get("line") for leg in legs if records[leg].get("line")]
         if not fallback:
             return 1
-        line = fallback[0]
+        line = dict(fallback[0], **extra)
         line["legs"] = summary
         print(json.dumps(line), flush=True)
         return 0 if line["parity"]["ok"] else 3
     value, name, d, gathered = max(candidates, key=lambda c: c[0])
-    line = dict(d)
+    line = dict(d, **extra)
     line["legs"] = summary
     line["config"] = dict(d["config"], chosen_leg=name,
                           choice="best of the legs whose time includes a collective (see `legs`; the no-collective "
@@ -718,6 +759,9 @@ def run_rank(args):
         layout_kind = "replicated" if l**4 * es * (1 + 4 / world) < 0.85 * HBM_BYTES else "inplace"
     if layout_kind == "inplace" and l % world:
         raise SystemExit("--layout inplace needs l divisible by the number of GPUs")
+    coalesced = layout_kind == "rows_rccl_coalesced"
+    if coalesced:
+        layout_kind = "rows_rccl"
     if layout_kind in ("rccl", "rows_rccl") and world > 1 and (single_dev or backend != "nccl") \
             and not os.environ.get("QS_AMD_RCCL_LIB"):       # (the test suite's stand-in transport lets ranks share a GPU)
         raise SystemExit(f"--layout {layout_kind} drives RCCL directly: one GPU per rank (not available in the one-device rehearsal)")
@@ -769,7 +813,7 @@ def run_rank(args):
         if use_dist:
             dist.broadcast_object_list(ids, src=0)         # 128 bytes, by the job's existing rendezvous
         with _StdoutToStderr():
-            rccl_comm = kernels.RcclComm(rank, world, ids[0])
+            rccl_comm = kernels.RcclComm(rank, world, ids[0], rows_coalesce=coalesced)
 
     if layout_kind == "single":
         out = torch.empty(u.shape, dtype=dtype, device=device)
@@ -802,7 +846,9 @@ def run_rank(args):
                 return rccl_comm.transform_two_body_rows(u, C, Ct, chunk_rows=args.chunk_rows, out=keep)
             layout = ("u sharded over its leading index and resident, out over its second (rows in, rows out): ONE C-ABI "
                       "call, input rows + result rows + O(l^3) per GPU, RCCL grouped send/recv per chunk of rows on its "
-                      "own stream under the next chunk's products")
+                      "own stream under the next chunk's products"
+                      + (", ONE message per peer and step (staging + strided copy)" if coalesced
+                         else ", one message per (peer, result row) landing in place"))
     elif layout_kind == "rccl":
         out_slab = torch.empty((p_hi - p_lo, l, l, l), dtype=dtype, device=device)
 

@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define QS_ABI_VERSION 3
+#define QS_ABI_VERSION 4
 
 enum {
     QS_OK = 0,
@@ -265,6 +265,18 @@ int qs_comm_abort(void* comm);
 int qs_comm_rank(void* comm);
 int qs_comm_world(void* comm);
 const char* qs_last_comm_error(void);
+/* Per-handle options (every rank of the communicator must choose the same):
+ *   "rows_coalesce" = 1: qs_transform_two_body_sharded_rows exchanges ONE
+ *     message per peer and step -- the peer's block of the send buffer as it
+ *     is; the received block goes through a staging area at the end of the
+ *     workspace and is put in place by one strided copy on the communicator's
+ *     stream -- instead of one message per peer and result row that lands in
+ *     place (0, the default).  Same results bit for bit; trades
+ *     jl (world - 1) chunk_rows M^2 elements of workspace and one extra pass
+ *     over the received rows for (world - 1) instead of jl (world - 1)
+ *     messages per step and direction.
+ * Unknown key: QS_ERR_BAD_EXTENT. */
+int qs_comm_set_option(void* comm, const char* key, int64_t value);
 
 /*
  * STATUS of the sharded entry points below: EXPERIMENTAL.  On REAL RCCL they
@@ -273,7 +285,13 @@ const char* qs_last_comm_error(void);
  * rank processes on one GPU, every ncclSend / ncclRecv the library posts
  * carried by a file-based stand-in for librccl (tests/cabi/mock_rccl.cpp: same
  * pairing and size rules, no asynchrony), results bit-identical to the
- * single-GPU transform; in addition worlds of 1..8 ranks are covered by CPU
+ * single-GPU transform, and by tests/test_gpu_async_transport.py: the ranks as
+ * THREADS of one process over a stream-ordered, asynchronous stand-in
+ * (tests/cabi/mock_rccl_async.cpp: ncclGroupEnd returns before anything has
+ * moved, every transfer is a device copy behind events of both sides, with an
+ * optional delay), which fails -- and is tested to fail -- when any one of
+ * the stream waits between the caller's stream and the communicator's stream
+ * is left out; in addition worlds of 1..8 ranks are covered by CPU
  * replays of the exchange plans (qs_sharded_exchange_plan,
  * qs_sharded_rows_exchange_plan) and by the same algorithms driven through
  * torch.distributed in the Python layer.  Unrun until an 8-GPU node: RCCL's own
@@ -354,6 +372,10 @@ int64_t qs_transform_two_body_sharded_rows_out_bytes(int dtype, int64_t L, int64
                                                      int world, int rank);
 int64_t qs_transform_two_body_sharded_rows_workspace(int dtype, int64_t L, int64_t M,
                                                      int64_t chunk_rows);
+/* The same for THIS handle: adds the staging area when the handle's option
+ * "rows_coalesce" is set (this is the size the call checks work_bytes against). */
+int64_t qs_comm_rows_workspace(void* comm, int dtype, int64_t L, int64_t M,
+                               int64_t chunk_rows);
 int qs_transform_two_body_sharded_rows(void* comm, int in_dtype, int dtype,
                                        const void* rows, const int64_t* in_starts,
                                        const void* C, const void* Ct,
@@ -370,6 +392,15 @@ int qs_transform_two_body_sharded_rows(void* comm, int in_dtype, int dtype,
 int qs_sharded_rows_exchange_plan(int64_t L, int64_t M, int world, int rank,
                                   const int64_t* in_starts, int64_t chunk_rows,
                                   int64_t* header, int64_t* table, int64_t table_rows);
+/* ... of the coalesced exchange ("rows_coalesce"): kind 0 send (one per peer:
+ * the peer's whole block of W), 3 receive into the staging area (buf_off =
+ * offset into it), 4 staging -> out_buffer behind the group (w_off = offset
+ * into the staging area, `rows` pieces of `count` elements, pitches count and
+ * L*M*M), 2 own rows as above. */
+int qs_sharded_rows_exchange_plan_coalesced(int64_t L, int64_t M, int world, int rank,
+                                            const int64_t* in_starts, int64_t chunk_rows,
+                                            int64_t* header, int64_t* table,
+                                            int64_t table_rows);
 
 /*
  * Which kernels the calling thread's most recent compute entry point launched,

@@ -55,6 +55,7 @@ SIGNATURES = {
     "qs_comm_rank": (c_int, [c_ptr]),
     "qs_comm_world": (c_int, [c_ptr]),
     "qs_last_comm_error": (ctypes.c_char_p, []),
+    "qs_comm_set_option": (c_int, [c_ptr, ctypes.c_char_p, c_i64]),
     "qs_transform_two_body_sharded_workspace": (c_i64, [c_int, c_i64, c_i64, c_int, c_int]),
     "qs_transform_two_body_sharded": (
         c_int, [c_ptr, c_int, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_i64, c_i64, c_i64, c_int, c_ptr]),
@@ -64,7 +65,9 @@ SIGNATURES = {
     "qs_transform_two_body_sharded_rows_workspace": (c_i64, [c_int, c_i64, c_i64, c_i64]),
     "qs_transform_two_body_sharded_rows": (
         c_int, [c_ptr, c_int, c_int, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_i64, c_ptr, c_i64, c_i64, c_i64, c_i64, c_ptr]),
+    "qs_comm_rows_workspace": (c_i64, [c_ptr, c_int, c_i64, c_i64, c_i64]),
     "qs_sharded_rows_exchange_plan": (c_int, [c_i64, c_i64, c_int, c_int, c_ptr, c_i64, c_ptr, c_ptr, c_i64]),
+    "qs_sharded_rows_exchange_plan_coalesced": (c_int, [c_i64, c_i64, c_int, c_int, c_ptr, c_i64, c_ptr, c_ptr, c_i64]),
     "qs_last_dispatch": (ctypes.c_char_p, []),
     "qs_tuning_set": (c_int, [ctypes.c_char_p, c_i64]),
     "qs_tuning_reset": (c_int, []),
@@ -72,7 +75,7 @@ SIGNATURES = {
     "qs_probe_stream_copy": (c_int, [c_ptr, c_ptr, c_i64, c_ptr]),
 }
 
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 
 class QsLibraryError(RuntimeError):

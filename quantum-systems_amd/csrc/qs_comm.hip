@@ -181,7 +181,18 @@ struct Comm {
     std::unique_ptr<Plan> plan;                // exchange plan of the most recent call (1.5 MB: on the heap, per handle)
     bool broken = false;                       // a call failed after its exchange had started: peers may be waiting in a
                                                // group this rank never completed -- only qs_comm_abort / destroy are left
+    int rows_coalesce = 0;                     // qs_comm_set_option("rows_coalesce"): the rows exchange as ONE message per peer and step
 };
+
+// TEST HOOK (tuning key "comm_drop_wait", a bit mask, thread-local like every tuning key): leave out one of the waits
+// that order the caller's stream and the communicator's stream.  The asynchronous stand-in transport of the test suite
+// (tests/cabi/mock_rccl_async.cpp) must then produce WRONG results -- the proof that it would catch such a mistake.
+//   1  rows: products of step t do not wait for the exchange of step t - 2 to have read their send block
+//   2  rows: the exchange of a step does not wait for the step's products
+//   4  rows: the closing products do not wait for the exchange
+//   8  slab entry: the closing product of a chunk does not wait for the chunk's rows
+//   16 slab entry: the exchange of a chunk does not wait for the chunk's products
+inline bool dropped(int bit) { return (g_tune.comm_drop_wait & bit) != 0; }
 
 // A failure once send / receive operations of this call may have been posted: the peers can be blocked in a group that
 // this rank will never complete.  The handle is marked, so that every later call fails at once instead of dead-locking
@@ -398,7 +409,7 @@ int qs_transform_two_body_sharded(void* comm, int dtype, const void* u_bslab, co
         // out[p][q, (r,s)] = Ct[q, :] . R[p][:, (r,s)] for our rows of chunk k, once they are complete
         const int64_t lo = plan.close_lo[k], n = plan.close_n[k];
         if (n <= 0) return QS_OK;
-        hipError_t ee = hipStreamWaitEvent(s, c->r_ready[k], 0);
+        hipError_t ee = dropped(8) ? hipSuccess : hipStreamWaitEvent(s, c->r_ready[k], 0);
         if (ee != hipSuccess) return hip_status(ee, "qs_transform_two_body_sharded: wait for rows");
         return matmul_checked(dtype, Ct, at(R, lo * L * MM), at(out_pslab, lo * M * MM), M, MM, L, L, MM, MM, n, 0, L * MM,
                          M * MM, 0, s);
@@ -413,7 +424,7 @@ int qs_transform_two_body_sharded(void* comm, int dtype, const void* u_bslab, co
             if (rc) return k ? fail_mid_exchange(c, rc) : rc;
         }
         e = hipEventRecord(c->x_ready[k], s);
-        if (e == hipSuccess) e = hipStreamWaitEvent(c->stream, c->x_ready[k], 0);
+        if (e == hipSuccess && !dropped(16)) e = hipStreamWaitEvent(c->stream, c->x_ready[k], 0);
         if (e != hipSuccess) {
             rc = hip_status(e, "qs_transform_two_body_sharded: chunk ready");
             return k ? fail_mid_exchange(c, rc) : rc;
@@ -518,9 +529,15 @@ inline int64_t clamp_rows(int64_t have, int64_t i0, int64_t ni) {
 // The operations of one step, in the order both sides of every pair post them (peer ascending; per peer the sends in
 // ascending j', the receives in ascending j'_loc).  kind 0 send (offset into W), 1 receive (offset into the result
 // buffer), 2 own rows (W -> buffer, `rows` pieces of `count` elements, pitches n*MM and L*MM).
+// COALESCED form (one message per peer and step instead of one per peer and result row): a peer's share of W is one
+// contiguous block anyway (W is stored [j'][i][(r,s)]), so its send is kind 0 with count = jc*n*MM; what the peer
+// computed for us arrives as ONE block [j'_loc][i][(r,s)] in the staging area (kind 3: r_off = offset into the staging
+// area) and is put in place by one strided copy on the communicator's stream behind the group (kind 4: x_off = offset
+// into the staging area, r_off = offset into the result buffer, `rows` pieces of `count` elements, pitches count and L*MM).
 template <typename F>
-int rows_step_ops(const RowsGeom& q, const int64_t* in_starts, int64_t ni, int64_t step, F&& emit) {
+int rows_step_ops(const RowsGeom& q, const int64_t* in_starts, int64_t ni, int64_t step, bool coalesce, F&& emit) {
     const int64_t i0 = step * ni, n = clamp_rows(q.il, i0, ni), MM = q.MM;
+    int64_t stage = 0;
     for (int g = 0; g < q.G; ++g) {
         const int64_t j_lo = part_lo(q.M, q.G, g), jc = part_lo(q.M, q.G, g + 1) - j_lo;
         const int64_t g_start = in_lo(in_starts, q.L, q.G, g);
@@ -530,10 +547,31 @@ int rows_step_ops(const RowsGeom& q, const int64_t* in_starts, int64_t ni, int64
                 if (int rc = emit(PlanOp{(int)step, g, 2, j_lo * n * MM, q.r0 + (q.i_start + i0) * MM, n * MM, q.jl})) return rc;
             continue;
         }
+        if (coalesce) {
+            if (jc > 0 && n > 0)
+                if (int rc = emit(PlanOp{(int)step, g, 0, j_lo * n * MM, 0, jc * n * MM, 1})) return rc;
+            if (q.jl > 0 && ng > 0) {
+                if (int rc = emit(PlanOp{(int)step, g, 3, 0, stage, q.jl * ng * MM, 1})) return rc;
+                stage += q.jl * ng * MM;
+            }
+            continue;
+        }
         for (int64_t j = 0; j < jc && n > 0; ++j)
             if (int rc = emit(PlanOp{(int)step, g, 0, (j_lo + j) * n * MM, 0, n * MM, 1})) return rc;
         for (int64_t j = 0; j < q.jl && ng > 0; ++j)
             if (int rc = emit(PlanOp{(int)step, g, 1, 0, q.r0 + (j * q.L + g_start + i0) * MM, ng * MM, 1})) return rc;
+    }
+    if (coalesce) {      // behind the group: the received blocks into place
+        stage = 0;
+        for (int g = 0; g < q.G; ++g) {
+            if (g == q.me) continue;
+            const int64_t g_start = in_lo(in_starts, q.L, q.G, g);
+            const int64_t ng = clamp_rows(in_lo(in_starts, q.L, q.G, g + 1) - g_start, i0, ni);
+            if (q.jl > 0 && ng > 0) {
+                if (int rc = emit(PlanOp{(int)step, g, 4, stage, q.r0 + (g_start + i0) * MM, ng * MM, q.jl})) return rc;
+                stage += q.jl * ng * MM;
+            }
+        }
     }
     return QS_OK;
 }
@@ -578,11 +616,33 @@ int64_t qs_transform_two_body_sharded_rows_workspace(int dtype, int64_t L, int64
     return (lm + ni * L * L * M + ni * L * MM + 2 * M * ni * MM + 8) * (int64_t)elem_size(dtype);
 }
 
+/* ... for THIS handle: with the option "rows_coalesce" the staging area of the coalesced exchange follows (what the
+ * peers send this rank in one step: at most jl (world - 1) chunk_rows M^2 elements, about one more send block) */
+int64_t qs_comm_rows_workspace(void* comm, int dtype, int64_t L, int64_t M, int64_t chunk_rows) {
+    if (!comm) return QS_ERR_NULL_POINTER;
+    const Comm* c = (const Comm*)comm;
+    const int64_t base = qs_transform_two_body_sharded_rows_workspace(dtype, L, M, chunk_rows);
+    if (base < 0 || !c->rows_coalesce) return base;
+    const int64_t jl = part_lo(M, c->world, c->rank + 1) - part_lo(M, c->world, c->rank);
+    return base + jl * (c->world - 1) * chunk_rows * M * M * (int64_t)elem_size(dtype);
+}
+
+/* Per-handle options.  "rows_coalesce" = 1: qs_transform_two_body_sharded_rows exchanges ONE message per peer and step
+ * (the peer's block of the send buffer as it is; the received block goes through a staging area of the workspace and is
+ * put in place by one strided copy on the communicator's stream) instead of one message per peer and result row that
+ * lands in place.  Same results bit for bit; every rank of the communicator must choose the same. */
+int qs_comm_set_option(void* comm, const char* key, int64_t value) {
+    if (!comm || !key) return QS_ERR_NULL_POINTER;
+    Comm* c = (Comm*)comm;
+    if (!strcmp(key, "rows_coalesce")) { c->rows_coalesce = value != 0; return QS_OK; }
+    return QS_ERR_BAD_EXTENT;
+}
+
 /* The exchange plan of one rank as numbers (no GPU, no RCCL): the CPU suite replays the plans of every rank of a world
  * with NumPy.  header: {i_start, il, jl, il_max, r0, out_elems, chunk_rows, nsteps}; table: one row
  * {step, peer, kind, w_off, buf_off, count, rows} per operation.  Returns the number of operations or an error. */
-int qs_sharded_rows_exchange_plan(int64_t L, int64_t M, int world, int rank, const int64_t* in_starts, int64_t chunk_rows,
-                                  int64_t* header, int64_t* table, int64_t table_rows) {
+static int rows_exchange_plan(int64_t L, int64_t M, int world, int rank, const int64_t* in_starts, int64_t chunk_rows,
+                              bool coalesce, int64_t* header, int64_t* table, int64_t table_rows) {
     if (!header || !table) return QS_ERR_NULL_POINTER;
     RowsGeom q;
     if (int rc = rows_geometry(q, L, M, world, rank, in_starts)) return rc;
@@ -592,7 +652,7 @@ int qs_sharded_rows_exchange_plan(int64_t L, int64_t M, int world, int rank, con
     memcpy(header, h, sizeof(h));
     int64_t nops = 0;
     for (int64_t t = 0; t < nsteps; ++t) {
-        int rc = rows_step_ops(q, in_starts, ni, t, [&](const PlanOp& o) -> int {
+        int rc = rows_step_ops(q, in_starts, ni, t, coalesce, [&](const PlanOp& o) -> int {
             if (nops >= table_rows) return QS_ERR_WORKSPACE;
             const int64_t row[7] = {o.chunk, o.peer, o.kind, o.x_off, o.r_off, o.count, o.rows};
             memcpy(table + 7 * nops, row, sizeof(row));
@@ -602,6 +662,19 @@ int qs_sharded_rows_exchange_plan(int64_t L, int64_t M, int world, int rank, con
         if (rc) return rc;
     }
     return (int)nops;
+}
+
+int qs_sharded_rows_exchange_plan(int64_t L, int64_t M, int world, int rank, const int64_t* in_starts, int64_t chunk_rows,
+                                  int64_t* header, int64_t* table, int64_t table_rows) {
+    return rows_exchange_plan(L, M, world, rank, in_starts, chunk_rows, false, header, table, table_rows);
+}
+
+/* ... of the coalesced exchange (qs_comm_set_option "rows_coalesce"): kind 0 send (one per peer), 3 receive into the
+ * staging area (buf_off = offset into it), 4 staging -> out_buffer behind the group (w_off = offset into the staging
+ * area, `rows` pieces of `count` elements, pitches count and L*M*M), 2 own rows as before. */
+int qs_sharded_rows_exchange_plan_coalesced(int64_t L, int64_t M, int world, int rank, const int64_t* in_starts,
+                                            int64_t chunk_rows, int64_t* header, int64_t* table, int64_t table_rows) {
+    return rows_exchange_plan(L, M, world, rank, in_starts, chunk_rows, true, header, table, table_rows);
 }
 
 int qs_transform_two_body_sharded_rows(void* comm, int in_dtype, int dtype, const void* rows, const int64_t* in_starts,
@@ -622,7 +695,7 @@ int qs_transform_two_body_sharded_rows(void* comm, int in_dtype, int dtype, cons
     const int64_t ni = chunk_rows >= 1 ? (chunk_rows > q.il_max ? q.il_max : chunk_rows)
                                        : rows_default_chunk(L, M, q.il_max, es);
     if (out_bytes < q.out_elems * (int64_t)es) return QS_ERR_WORKSPACE;
-    if (work_bytes < qs_transform_two_body_sharded_rows_workspace(dtype, L, M, ni)) return QS_ERR_WORKSPACE;
+    if (work_bytes < qs_comm_rows_workspace(comm, dtype, L, M, ni)) return QS_ERR_WORKSPACE;
     if (current_device() != c->device) return QS_ERR_BAD_EXTENT;      // the communicator belongs to another device
     if (c->broken) {
         snprintf(g_comm_err, sizeof(g_comm_err), "the communicator was left broken by an earlier failed call: abort / destroy it");
@@ -637,6 +710,8 @@ int qs_transform_two_body_sharded_rows(void* comm, int in_dtype, int dtype, cons
     void* T1 = at(CT, lm);
     void* T2 = at(T1, ni * L * L * M);
     void* W[2] = {at(T2, ni * L * MM), at(T2, ni * L * MM + M * ni * MM)};
+    void* S = at(T2, ni * L * MM + 2 * M * ni * MM);     // staging of the coalesced exchange
+    const bool coalesce = c->rows_coalesce != 0;
     bool posted = false;                                 // anything handed to RCCL yet?
     auto fail = [&](int rc) { return posted ? fail_mid_exchange(c, rc) : rc; };
 
@@ -647,7 +722,7 @@ int qs_transform_two_body_sharded_rows(void* comm, int in_dtype, int dtype, cons
         const int64_t i0 = t * ni, n = clamp_rows(q.il, i0, ni);
         hipError_t e = hipSuccess;
         // W[w] was last read by the exchange of step t - 2
-        if (t >= 2) e = hipStreamWaitEvent(s, c->r_ready[w], 0);
+        if (t >= 2 && !dropped(1)) e = hipStreamWaitEvent(s, c->r_ready[w], 0);
         if (e != hipSuccess) return fail(hip_status(e, "qs_transform_two_body_sharded_rows: send buffer free"));
         if (n > 0) {
             const void* src = (const char*)rows + (size_t)(i0 * L * L * L) * ies;
@@ -663,11 +738,12 @@ int qs_transform_two_body_sharded_rows(void* comm, int in_dtype, int dtype, cons
             if (rc) return fail(rc);
         }
         e = hipEventRecord(c->x_ready[w], s);
-        if (e == hipSuccess) e = hipStreamWaitEvent(c->stream, c->x_ready[w], 0);
+        if (e == hipSuccess && !dropped(2)) e = hipStreamWaitEvent(c->stream, c->x_ready[w], 0);
         if (e != hipSuccess) return fail(hip_status(e, "qs_transform_two_body_sharded_rows: chunk ready"));
         if (int grc = rccl_status(rccl().group_start(), "ncclGroupStart")) return fail(grc);
         posted = true;
-        rc = rows_step_ops(q, in_starts, ni, t, [&](const PlanOp& o) -> int {
+        bool group_open = true;
+        rc = rows_step_ops(q, in_starts, ni, t, coalesce, [&](const PlanOp& o) -> int {
             if (o.kind == 2) {
                 hipError_t ce = hipMemcpy2DAsync(at(out_buffer, o.r_off), (size_t)(L * MM) * es, at(W[w], o.x_off),
                                                  (size_t)o.count * es, (size_t)o.count * es, (size_t)o.rows,
@@ -677,17 +753,30 @@ int qs_transform_two_body_sharded_rows(void* comm, int in_dtype, int dtype, cons
             if (o.kind == 0)
                 return rccl_status(rccl().send(at(W[w], o.x_off), (size_t)(o.count * width), kNcclFloat64, o.peer, c->nccl,
                                                c->stream), "ncclSend");
-            return rccl_status(rccl().recv(at(out_buffer, o.r_off), (size_t)(o.count * width), kNcclFloat64, o.peer, c->nccl,
-                                           c->stream), "ncclRecv");
+            if (o.kind == 1)
+                return rccl_status(rccl().recv(at(out_buffer, o.r_off), (size_t)(o.count * width), kNcclFloat64, o.peer, c->nccl,
+                                               c->stream), "ncclRecv");
+            if (o.kind == 3)
+                return rccl_status(rccl().recv(at(S, o.r_off), (size_t)(o.count * width), kNcclFloat64, o.peer, c->nccl,
+                                               c->stream), "ncclRecv");
+            // kind 4: the group is complete (these follow every send / receive of the step): received blocks into place
+            if (group_open) {
+                group_open = false;
+                if (int grc = rccl_status(rccl().group_end(), "ncclGroupEnd")) return grc;
+            }
+            hipError_t ce = hipMemcpy2DAsync(at(out_buffer, o.r_off), (size_t)(L * MM) * es, at(S, o.x_off), (size_t)o.count * es,
+                                             (size_t)o.count * es, (size_t)o.rows, hipMemcpyDeviceToDevice, c->stream);
+            return ce == hipSuccess ? QS_OK : hip_status(ce, "qs_transform_two_body_sharded_rows: staged rows");
         });
-        if (rc) { rccl().group_end(); return fail(rc); }
-        if (int grc = rccl_status(rccl().group_end(), "ncclGroupEnd")) return fail(grc);
+        if (rc) { if (group_open) rccl().group_end(); return fail(rc); }
+        if (group_open)
+            if (int grc = rccl_status(rccl().group_end(), "ncclGroupEnd")) return fail(grc);
         e = hipEventRecord(c->r_ready[w], c->stream);
         if (e != hipSuccess) return fail(hip_status(e, "qs_transform_two_body_sharded_rows: chunk sent"));
     }
     // every received row is complete only now: the closing products follow the whole exchange
     hipError_t e = hipEventRecord(c->done, c->stream);
-    if (e == hipSuccess) e = hipStreamWaitEvent(s, c->done, 0);
+    if (e == hipSuccess && !dropped(4)) e = hipStreamWaitEvent(s, c->done, 0);
     if (e != hipSuccess) return fail(hip_status(e, "qs_transform_two_body_sharded_rows: join"));
     // I:  out[p][i', (r,s)] = Ct[i', i] R[p][i, (r,s)], row by row, packed from the start of the buffer
     for (int64_t p = 0; p < q.jl; ++p) {
@@ -695,7 +784,8 @@ int qs_transform_two_body_sharded_rows(void* comm, int in_dtype, int dtype, cons
                             0, 0, 0, 0, s);
         if (rc) return rc;
     }
-    note_dispatch("rccl grouped send/recv (%lld steps of %lld rows)", (long long)nsteps, (long long)ni);
+    note_dispatch("rccl grouped send/recv (%lld steps of %lld rows%s)", (long long)nsteps, (long long)ni,
+                  coalesce ? ", one message per peer and step" : "");
     return QS_OK;
 }
 

@@ -181,6 +181,8 @@ struct Tuning {
     int pair4c_stream = 1;       // (kept for old tuning scripts: the whole-pair form it switched to is gone)
     int pair4c = 1;              // complex128 up to 56 orbitals: both fused passes on the two-items-per-instruction kernel (qs_pair4c.hip):
                                  // 1 automatic, 2 wherever it exists, 0 off
+    int comm_drop_wait = 0;      // TEST HOOK (qs_comm.hip): bit mask of stream waits of the sharded entry points to leave out -- the negative
+                                 // test of the asynchronous stand-in transport; never set outside tests/
     int sandwich = 1;            // 4-wide fused passes of a small-basis transform: 0 off, 1 both (d, c) and (b, a), 2 (d, c) only, 3 (b, a) only;
                                  // tuning runs, wherever the kernel exists (not only where it measured faster): 4 both, 5 (d, c) only, 6 (b, a) only
 };

@@ -614,7 +614,7 @@ class RcclComm:
         check(_lib.load().qs_comm_unique_id(ctypes.cast(buf, ctypes.c_void_p)), "qs_comm_unique_id")
         return bytes(buf)
 
-    def __init__(self, rank, world, unique_id):
+    def __init__(self, rank, world, unique_id, rows_coalesce=False):
         import ctypes
 
         if len(unique_id) != 128:
@@ -624,6 +624,13 @@ class RcclComm:
         check(_lib.load().qs_comm_init(ctypes.byref(self._handle), int(rank), int(world),
                                        ctypes.cast(buf, ctypes.c_void_p)), "qs_comm_init")
         self.rank, self.world = int(rank), int(world)
+        if rows_coalesce:
+            self.set_option("rows_coalesce", 1)
+
+    def set_option(self, key, value):
+        """Per-handle option (``qs_comm_set_option``; every rank must choose the same).  ``rows_coalesce`` = 1: the rows
+        exchange as ONE message per peer and step through a staging area instead of one per peer and result row."""
+        check(_lib.load().qs_comm_set_option(self._handle, key.encode(), int(value)), "qs_comm_set_option")
 
     def close(self):
         if self._handle:
@@ -685,7 +692,7 @@ class RcclComm:
         elif (not isinstance(out, torch.Tensor) or out.dtype != dt or out.numel() * es < out_bytes
               or not out.is_contiguous() or out.device != rows.device):
             raise ValueError(f"`out` must be a contiguous {dt} buffer of at least {out_bytes // es} elements")
-        nbytes = check(lib.qs_transform_two_body_sharded_rows_workspace(code, L, M, ni), "workspace query")
+        nbytes = check(lib.qs_comm_rows_workspace(self._handle, code, L, M, ni), "workspace query")
         with _on_device_of(rows, C, Ct, out):
             work = workspace.get(nbytes, rows.device)
             _ran(

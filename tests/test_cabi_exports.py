@@ -50,7 +50,7 @@ def test_every_declared_symbol_is_exported_and_bound(lib):
 
 
 def test_abi_version_and_error_strings(lib):
-    assert lib.qs_abi_version() == 3
+    assert lib.qs_abi_version() == 4
     assert lib.qs_error_string(0) == b"ok"
     for code in range(-7, 0):
         assert len(lib.qs_error_string(code)) > 0

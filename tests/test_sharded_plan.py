@@ -95,12 +95,13 @@ def test_replayed_exchange_gives_the_transform(world, L, M, nchunks, cplx):
 # ---------------------------------------------------------------------------------------------------------------
 
 
-def rows_plan_of(lib, L, M, world, rank, starts, chunk_rows):
+def rows_plan_of(lib, L, M, world, rank, starts, chunk_rows, coalesced=False):
     header = (ctypes.c_int64 * 8)()
     cap = 64 + 4 * (M + world) * (L + 1)
     table = (ctypes.c_int64 * (7 * cap))()
     p_starts = (ctypes.c_int64 * (world + 1))(*starts) if starts is not None else None
-    n = lib.qs_sharded_rows_exchange_plan(L, M, world, rank, p_starts, chunk_rows, header, table, cap)
+    fn = lib.qs_sharded_rows_exchange_plan_coalesced if coalesced else lib.qs_sharded_rows_exchange_plan
+    n = fn(L, M, world, rank, p_starts, chunk_rows, header, table, cap)
     assert n >= 0, n
     keys = ("i_start", "il", "jl", "il_max", "r0", "out_elems", "chunk_rows", "nsteps")
     pl = dict(zip(keys, (int(x) for x in header)))
@@ -115,12 +116,15 @@ def rows_plan_of(lib, L, M, world, rank, starts, chunk_rows):
     (11, 11, 0, False, False),      # chunk_rows <= 0: the library's own choice
 ])
 @pytest.mark.parametrize("second_index", [False, True])
-def test_replayed_rows_exchange_gives_the_transform(world, L, M, chunk_rows, cplx, doubled, second_index):
+@pytest.mark.parametrize("coalesced", [False, True])
+def test_replayed_rows_exchange_gives_the_transform(world, L, M, chunk_rows, cplx, doubled, second_index, coalesced):
     # Replay of every rank's plan with NumPy: per step the three local products into the send block W[j'][i][(r,s)],
     # the grouped sends / receives matched pairwise in issue order, the own-rows copy; after the last step the closing
     # product row by row INSIDE the result buffer.  Checked: every rank's result rows against the oracle (both
     # shardings: the routine is symmetric in the two leading indices), nothing read before it arrived, and the
-    # in-buffer product never overwriting a received row that is still to be read.
+    # in-buffer product never overwriting a received row that is still to be read.  coalesced: ONE message per peer and
+    # step (the handle's option "rows_coalesce"): the peer's block of W as it is, received into a staging area whose size
+    # is the bound qs_comm_rows_workspace adds, put in place by strided copies behind the group.
     from quantum_systems_amd import _lib
     from quantum_systems_amd.sharded import SlabPartition
 
@@ -138,7 +142,7 @@ def test_replayed_rows_exchange_gives_the_transform(world, L, M, chunk_rows, cpl
     starts = SlabPartition(L // 2, world).doubled().starts if doubled else None
     ipart = SlabPartition(L, world, starts)
     jpart = SlabPartition(M, world)
-    plans = [rows_plan_of(lib, L, M, world, r, starts, chunk_rows) for r in range(world)]
+    plans = [rows_plan_of(lib, L, M, world, r, starts, chunk_rows, coalesced) for r in range(world)]
     ni, nsteps = plans[0]["chunk_rows"], plans[0]["nsteps"]
     for r, pl in enumerate(plans):
         assert (pl["i_start"], pl["i_start"] + pl["il"]) == ipart.bounds(r) and pl["jl"] == jpart.count(r)
@@ -157,16 +161,27 @@ def test_replayed_rows_exchange_gives_the_transform(world, L, M, chunk_rows, cpl
             t2 = np.einsum("ijcd,cr,ds->ijrs", rows, C, C)                  # d, c
             W = np.einsum("kj,ijrs->kirs", Ct, t2)                          # J: W[j', i, r, s]
             Ws.append(np.ascontiguousarray(W).reshape(-1))
-        sends, recvs = {}, {}
+        sends, recvs, scatters = {}, {}, []
+        stages = [np.full(pl["jl"] * (world - 1) * ni * MM, np.nan, dtype=ref.dtype) for pl in plans]
         for r, pl in enumerate(plans):
             n = max(0, min(ni, pl["il"] - t * ni))
+            group_closed = False
             for (step, peer, kind, w_off, b_off, count, nrows) in pl["ops"]:
                 if step != t:
                     continue
+                assert kind in ((0, 2, 3, 4) if coalesced else (0, 1, 2))
+                assert not (group_closed and kind != 4)                   # the copies out of the staging area come last
                 if kind == 0:
                     sends.setdefault((r, peer), []).append((w_off, count))
+                    assert not coalesced or len(sends[(r, peer)]) == 1     # one message per peer and step
                 elif kind == 1:
                     recvs.setdefault((peer, r), []).append((b_off, count))
+                elif kind == 3:
+                    assert b_off + count <= stages[r].size                  # inside the staging area the workspace query adds
+                    recvs.setdefault((peer, r), []).append((b_off, count))
+                elif kind == 4:
+                    group_closed = True
+                    scatters.append((r, w_off, b_off, count, nrows))
                 else:
                     assert peer == r and count == n * MM
                     for i in range(nrows):
@@ -176,7 +191,12 @@ def test_replayed_rows_exchange_gives_the_transform(world, L, M, chunk_rows, cpl
             got = recvs[(src, dst)]
             assert [c for (_, c) in msgs] == [c for (_, c) in got], (src, dst)
             for (w_off, count), (b_off, _) in zip(msgs, got):
-                bufs[dst][b_off: b_off + count] = Ws[src][w_off: w_off + count]
+                (stages if coalesced else bufs)[dst][b_off: b_off + count] = Ws[src][w_off: w_off + count]
+        for (r, s_off, b_off, count, nrows) in scatters:
+            for i in range(nrows):
+                piece = stages[r][s_off + i * count: s_off + (i + 1) * count]
+                assert not np.isnan(piece).any()
+                bufs[r][b_off + i * L * MM: b_off + i * L * MM + count] = piece
     for r, pl in enumerate(plans):
         buf, r0, jl = bufs[r], pl["r0"], pl["jl"]
         assert not np.isnan(buf[r0: r0 + jl * L * MM]).any()                # every received element was delivered
