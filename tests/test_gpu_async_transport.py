@@ -47,7 +47,10 @@ def built(tmp_path_factory):
 
 def run_demo(built, world, L, M, mode, chunk, coalesce, drop, stall_us, entry, delay_us):
     mock, exe = built
-    env = dict(os.environ, QS_AMD_RCCL_LIB=mock, QS_MOCK_RCCL_DELAY_US=str(delay_us))
+    # every stream of the process on a hardware queue of its own: with the runtime's default of four, streams share queues
+    # and a delay kernel (or a stalled stream) holds back whatever was enqueued behind it on the same queue -- which would
+    # serialise exactly the races this transport exists to expose
+    env = dict(os.environ, QS_AMD_RCCL_LIB=mock, QS_MOCK_RCCL_DELAY_US=str(delay_us), GPU_MAX_HW_QUEUES="64")
     cmd = [exe] + [str(x) for x in (world, L, M, mode, chunk, coalesce, drop, stall_us, entry)]
     res = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
     return res.returncode, res.stdout + res.stderr
