@@ -224,6 +224,9 @@ int qs_tuning_set(const char* key, int64_t value) {
     if (!strcmp(key, "pair4c_stream")) { g_tune.pair4c_stream = (int)value; return QS_OK; }
     if (!strcmp(key, "pair4c")) { g_tune.pair4c = (int)value; return QS_OK; }
     if (!strcmp(key, "sandwich")) { g_tune.sandwich = (int)value; return QS_OK; }
+    if (!strcmp(key, "gemm_strip")) { g_tune.gemm_strip = (int)value; return QS_OK; }
+    if (!strcmp(key, "gemm_strip_w")) { g_tune.gemm_strip_w = (int)value; return QS_OK; }
+    if (!strcmp(key, "gemm_fast_unaligned")) { g_tune.gemm_fast_unaligned = (int)value; return QS_OK; }
     if (!strcmp(key, "comm_drop_wait")) { g_tune.comm_drop_wait = (int)value; return QS_OK; }
     if (!strcmp(key, "sandwich_mode")) { g_tune.sandwich_mode = (int)value; return QS_OK; }
     if (!strcmp(key, "sandwich_t2")) { g_tune.sandwich_t2 = (int)value; return QS_OK; }

@@ -135,6 +135,11 @@ int pair4c_try(int dtype, const void* in, void* out, const void* R, int64_t r_sk
                int64_t l_sp, int64_t l_sa, int64_t nitems, int64_t L, int64_t M, int64_t in_item, int64_t in_row,
                int64_t in_col, int64_t out_item, int64_t out_row, int64_t out_col, int tensor_is_b, hipStream_t stream);
 
+// Strip kernels (qs_gemm_strip.hip): same return convention; general_cost as for gemm_fast_try.
+int gemm_strip_try(int dtype, const double* A, const double* B, double* C, int64_t m, int64_t n, int64_t k, int64_t lda,
+                   int64_t ldb, int64_t ldc, int64_t batch, int64_t sa, int64_t sb, int64_t sc, int accumulate,
+                   double general_cost, hipStream_t stream);
+
 // Short-and-wide streaming product (qs_gemm_skinny.hip): same return convention.
 int gemm_skinny_try(int dtype, const double* A, const double* B, double* C, int64_t m, int64_t n,
                     int64_t k, int64_t lda, int64_t ldb, int64_t ldc, int64_t batch, int accumulate,
@@ -181,6 +186,10 @@ struct Tuning {
     int pair4c_stream = 1;       // (kept for old tuning scripts: the whole-pair form it switched to is gone)
     int pair4c = 1;              // complex128 up to 56 orbitals: both fused passes on the two-items-per-instruction kernel (qs_pair4c.hip):
                                  // 1 automatic, 2 wherever it exists, 0 off
+    int gemm_strip = 1;          // strip kernels (qs_gemm_strip.hip: the small extent of a product, <= 256, covered by ONE tile to the next
+                                 // multiple of 16, eight waves): 0 never, 1 by estimated time, 2 wherever they exist
+    int gemm_strip_w = 0;        // (tuning runs: relative rate of the strip kernels in percent, 0 = the built-in weights)
+    int gemm_fast_unaligned = 1; // 16-byte items of the VALU-free kernel's edge form also at odd strides / extents (0: 8-byte items there)
     int comm_drop_wait = 0;      // TEST HOOK (qs_comm.hip): bit mask of stream waits of the sharded entry points to leave out -- the negative
                                  // test of the asynchronous stand-in transport; never set outside tests/
     int sandwich = 1;            // 4-wide fused passes of a small-basis transform: 0 off, 1 both (d, c) and (b, a), 2 (d, c) only, 3 (b, a) only;

@@ -38,6 +38,7 @@
 #include <cmath>
 
 #include "qs_common.h"
+#include "qs_fast_items.h"
 
 namespace qs {
 
@@ -503,6 +504,13 @@ int gemm_f64(const double* A, const double* B, double* C, int64_t m, int64_t n, 
                 const int fc = pick_shape(fit, nfit, m, n, batch, &fcost);
                 if (g_tune.gemm_fit == 2 || fcost < cost) { fit_cfg = fc; cost = fcost; }
             }
+        }
+        {   // strip kernels (qs_gemm_strip.hip): the small extent of the product covered by one tile to the next multiple of 16
+            const bool even = vec && aligned(C, 16) && !(ldc & 1) && !(sc & 1);
+            const double fast = gemm_fast_estimate(QS_F64, m, n, k, batch, even);
+            const double gen = cost / kGeneralRelativeRate;
+            rc = gemm_strip_try(QS_F64, A, B, C, m, n, k, lda, ldb, ldc, batch, sa, sb, sc, accumulate, fast < gen ? fast : gen, stream);
+            if (rc != 1) return rc;
         }
         rc = gemm_fast_try(QS_F64, A, B, C, m, n, k, lda, ldb, ldc, batch, sa, sb, sc,
                            accumulate, g.group_along_m, g_tune.gemm_fit == 2 && fit_cfg ? 0.0 : cost / kGeneralRelativeRate, stream);

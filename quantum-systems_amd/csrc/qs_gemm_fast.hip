@@ -45,6 +45,7 @@
 #include <cmath>
 
 #include "qs_common.h"
+#include "qs_fast_items.h"
 
 // Epilogue stores are non-temporal: the product's output is read again only by the NEXT contraction, after the
 // whole tensor has passed through the caches (same-box A/B, three alternating runs each: l = 256 66.9-67.2 ->
@@ -59,9 +60,6 @@
 #endif
 
 namespace qs {
-
-typedef double f64x4 __attribute__((ext_vector_type(4)));
-typedef double f64x2 __attribute__((ext_vector_type(2)));
 
 struct FastArgs {
     const double* A;
@@ -78,55 +76,6 @@ struct FastArgs {
     int group_along_m;
     int accumulate;
 };
-
-// Work item of virtual block `v` of a `total`-block grid: XCD x (= v % 8) owns
-// the x-th contiguous chunk of the work list; bijective for every `total`.
-__device__ __forceinline__ unsigned xcd_chunked_index_fast(unsigned v, unsigned total) {
-    const unsigned xcd = v & 7u, slot = v >> 3;
-    const unsigned q = total >> 3, r = total & 7u;
-    const unsigned base = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
-    return base + slot;
-}
-
-// value known to be wave-uniform -> scalar registers
-__device__ __forceinline__ uint64_t uniform64(uint64_t x) {
-    const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)x);
-    const uint32_t hi = __builtin_amdgcn_readfirstlane((uint32_t)(x >> 32));
-    return ((uint64_t)hi << 32) | lo;
-}
-
-// One global item (16 or 8 bytes) at scalar base + 32-bit lane offset, buffer form:
-// dwords at lane offsets >= `room` come back as 0 (raw buffer range check).
-template <bool V16>
-struct FastItem;
-template <>
-struct FastItem<true> {
-    typedef f64x2 type;
-    static __device__ __forceinline__ type load(uint64_t base, unsigned room, unsigned lane_off) {
-        typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-        const auto rsrc = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void*>(base), (short)0,
-                                                            (int)room, 0x00020000);
-        const u32x4 raw = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)lane_off, 0, 0);
-        return __builtin_bit_cast(f64x2, raw);
-    }
-};
-template <>
-struct FastItem<false> {
-    typedef double type;
-    static __device__ __forceinline__ type load(uint64_t base, unsigned room, unsigned lane_off) {
-        typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
-        const auto rsrc = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void*>(base), (short)0,
-                                                            (int)room, 0x00020000);
-        const u32x2 raw = __builtin_amdgcn_raw_buffer_load_b64(rsrc, (int)lane_off, 0, 0);
-        return __builtin_bit_cast(double, raw);
-    }
-};
-
-// bytes from p to end, saturated to 32 bits (scalar ALU: both operands are wave-uniform)
-__device__ __forceinline__ unsigned bytes_left(uint64_t end, uint64_t p) {
-    const uint64_t d = end > p ? end - p : 0;
-    return d > 0xFFFFFFFFull ? 0xFFFFFFFFu : (unsigned)d;
-}
 
 template <bool CX, int TM, int TN, bool VEC, bool EDGE>
 __global__ __launch_bounds__(256, 2)
@@ -368,11 +317,16 @@ void gemm_fast_kernel(const FastArgs g) {
                     } else if constexpr (VEC) {
 #pragma unroll
                         for (int jp = 0; jp < TN / 2; ++jp) {
-                            if (row_ok && (!guard || col_l + jp * 32 < g.n)) {   // n is even in this form
+                            if (row_ok && (!guard || col_l + jp * 32 + 1 < g.n)) {
                                 f64x2* dst = reinterpret_cast<f64x2*>(crow + jp * 32);
                                 f64x2 v2 = f64x2{acc[0][i][2 * jp][r], acc[0][i][2 * jp + 1][r]};
                                 if constexpr (add) v2 += *dst;
                                 QS_FAST_STORE(dst, v2);
+                            } else if (guard && row_ok && col_l + jp * 32 < g.n) {   // odd n: the last column alone
+                                double* dst = crow + jp * 32;
+                                double v1 = acc[0][i][2 * jp][r];
+                                if constexpr (add) v1 += *dst;
+                                *dst = v1;
                             }
                         }
                     } else {
@@ -556,6 +510,29 @@ int pick_fast_shape(const FastShape (&cand)[N], int64_t m, int64_t n, int64_t ba
 }
 }  // namespace
 
+double gemm_fast_estimate(int dtype, int64_t m, int64_t n, int64_t k, int64_t batch, bool even) {
+    if (!g_tune.gemm_fast) return 1e300;
+    const bool cx = dtype == QS_C128;
+    const double slots = 2.0 * device_cu_count();
+    auto whole = [&](int bm, int bn, double w) {
+        const double tiles = (double)(m / bm) * (double)(n / bn) * (double)batch;
+        const double rounds = tiles > 8 * slots ? tiles / slots : ceil(tiles / slots);
+        return rounds * bm * bn / w;
+    };
+    if (!cx && even && k % 16 == 0) {
+        if (m % 128 == 0 && n % 128 == 0) return whole(128, 128, 1.0);
+        if (m % 64 == 0 && n % 128 == 0) return whole(64, 128, 0.93);
+    }
+    if (cx) {
+        if (k % 8 == 0 && m % 64 == 0 && n % 64 == 0) return whole(64, 64, 0.95);
+        return 1e300;
+    }
+    double cost = 1e300;
+    pick_fast_shape(kF64Shapes, m, n, batch, &cost);
+    if (!even && !g_tune.gemm_fast_unaligned) cost /= 0.85;
+    return cost;
+}
+
 // Returns QS_OK after launching, or 1 when the product does not qualify
 // (caller falls back to the general kernel).
 int gemm_fast_try(int dtype, const double* A, const double* B, double* C, int64_t m, int64_t n,
@@ -569,8 +546,12 @@ int gemm_fast_try(int dtype, const double* A, const double* B, double* C, int64_
     if (32 * lda * esz + 256 >= (int64_t(1) << 32)) return 1;
     if (m >= (int64_t(1) << 31) - 256 || n >= (int64_t(1) << 31) - 256 || k >= (int64_t(1) << 31) - 256) return 1;
     // 16-byte accesses: aligned bases, even strides (complex elements are 16 bytes by themselves)
-    const bool vec = cx || (aligned(A, 16) && aligned(B, 16) && aligned(C, 16) && !(lda & 1) && !(ldb & 1) &&
-                            !(ldc & 1) && !(sa & 1) && !(sb & 1) && !(sc & 1) && !(n & 1));
+    // gfx950 carries out 16-byte buffer loads and global stores at ANY 8-byte-aligned address (tools/probe_unaligned.hip), so odd
+    // strides and extents -- every odd basis size -- stage with 16-byte items too (g_tune.gemm_fast_unaligned = 0: 8-byte items
+    // there, the rule of rounds 1-3); LDS accesses stay 16-byte aligned (the stage layout does not depend on the strides).
+    const bool even = aligned(A, 16) && aligned(B, 16) && aligned(C, 16) && !(lda & 1) && !(ldb & 1) &&
+                      !(ldc & 1) && !(sa & 1) && !(sb & 1) && !(sc & 1) && !(n & 1);
+    const bool vec = cx || even || g_tune.gemm_fast_unaligned != 0;
 #define QS_FAST(CXF, TMF, TNF, VECF, EDGEF)                                                          \
     return launch_fast<CXF, TMF, TNF, VECF, EDGEF>(A, B, C, m, n, k, lda, ldb, ldc, batch, sa, sb, sc, \
                                                     accumulate, group_along_m, stream)

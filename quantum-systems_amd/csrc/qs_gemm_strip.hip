@@ -1,0 +1,499 @@
+// Strip kernels: the VALU-free tiled product for extents OFF the tile grid (round 4; VERDICT r03 "next" 2).
+//
+// Every contraction of the four-index transform has ONE small extent -- the basis size -- and one huge one:
+//   d      T1[(abc), s]   = u[(abc), d] C[d, s]            m = L^3 rows,  n = M columns (small),  B = C shared
+//   c,b,a  out[q, (cols)] = Ct[q, b] X[b, (cols)]          m = M rows (small), n = M ... M^3 columns, A = Ct shared
+// The 128 x 128 (or 160 x 64, ...) tiles of qs_gemm_fast.hip quantise BOTH extents: a basis of 130 orbitals pays for 192
+// columns in d and c and 160 rows in c, b, a (x 1.44 over the transform, profiles/r03_mid_size_shapes.txt), and its short tile
+// lists run small tiles at ~0.75 of the full-tile rate.  Here the small extent is covered by ONE tile to the next multiple of 16
+// (T = ceil(extent / 16) <= 16 row or column blocks), and the huge extent is cut into 128-wide pieces:
+//   FORM 0 ("tall"):  tile = (16 T rows = all of m) x 128 columns; the eight waves sit side by side, each 16 columns wide,
+//                     every wave multiplies ALL T row blocks of A (shared through LDS) with its own B fragment;
+//                     the columns are VIRTUAL: column j of the product is column j % W of batch entry j / W, so a batch of
+//                     narrow products (contraction c: L^2 products of M columns each) tiles as ONE long row of columns --
+//                     no padding of the column extent at all;
+//   FORM 1 ("wide"):  tile = 128 rows x (16 T columns = all of n); the eight waves are stacked, each 16 rows high, every
+//                     wave multiplies its own A fragment with ALL T column blocks of B (the coefficient matrix, shared).
+// One workgroup of eight waves per CU (two waves per SIMD), persistent over an XCD-chunked tile list.  The K loop is the one
+// of qs_gemm_fast.hip: no VALU instruction (buffer loads with SGPR descriptors, scalar bases advanced on the scalar ALU, one
+// loop-invariant lane offset; LDS addresses one VGPR + immediates), 16-deep stages double-buffered in LDS, global data two
+// stages ahead in registers, rotated fragment schedule, k-steps of a tile's last stage beyond K skipped.  Rows / columns
+// beyond the small extent multiply whatever the loads returned (zeros past the end of an operand: buffer range check) and
+// are never stored; k >= K is zeroed in registers before the last stage is written to LDS.  Every element is the same chain
+// of fused multiply-adds in increasing k as in the other tiled kernels: results are bit-identical (tests/test_gpu_kernels.py).
+// Global items are 16 bytes (two adjacent elements) at ANY 8-byte-aligned address -- gfx950 carries such buffer loads out
+// (tools/probe_unaligned.hip), so odd basis sizes stage like even ones; an odd column segment gets one dummy virtual column
+// so that an item never straddles two segments.  (VEC = false, 8-byte items, is kept for A/B runs: -DQS_STRIP_ITEMS8.)
+
+#include <type_traits>
+
+#include <cmath>
+#include <cstdlib>
+
+#include "qs_common.h"
+#include "qs_fast_items.h"
+
+namespace qs {
+
+struct StripArgs {
+    const double* A;
+    const double* B;
+    double* C;
+    int64_t lda, ldb, ldc;   // elements
+    int64_t sb, sc;          // FORM 0: distance between the column segments (batch entries) of B and of C
+    uint64_t a_end, b_end;   // one past the last byte of each operand
+    int64_t big;             // FORM 0: virtual columns (segments x W);  FORM 1: rows m
+    int64_t W;               // FORM 0: columns per segment
+    int64_t Wp;              // FORM 0: W rounded up to even: the width of a segment in VIRTUAL columns -- an odd segment gets one
+                             // dummy column at its end, so that a 16-byte item (two adjacent columns) never straddles two segments
+    int small;               // FORM 0: rows m (of A and of the result);  FORM 1: columns n
+    int k, nk;               // K, ceil(K / 16)
+    unsigned total;          // tiles
+    int stagger_slots;       // > 1: workgroup b starts (b / 8) % slots phase steps late, so that the epilogues of the CUs --
+    int stagger_cycles;      // 147 KB of stores each, every tile -- do not reach memory chip-wide at the same moment (cycles per step)
+};
+
+template <int FORM, int T, bool VEC, int SETS>
+__global__ __launch_bounds__(512, 1)
+void gemm_strip_kernel(const StripArgs g) {
+    constexpr int KT = 16, KS = 4, NT = 512, SA = KT + 2;
+    constexpr int EPI = VEC ? 2 : 1;                          // tensor elements per global item
+    constexpr unsigned IB = 8u * EPI;                         // bytes per item
+    constexpr int IPR_A = KT / EPI;                           // items per A row of a stage
+    constexpr int RA = NT / IPR_A;                            // A rows covered by one item step (64 / 32)
+    constexpr int A_ROWS = FORM == 0 ? 16 * T : 128;
+    constexpr int NA = (A_ROWS + RA - 1) / RA;                // item steps of the A stage
+    constexpr int B_COLS = FORM == 0 ? 128 : 16 * T;
+    constexpr int IPR_B = B_COLS / EPI;                       // items per B row
+    constexpr int B_ITEMS = KT * IPR_B;
+    constexpr int NB = (B_ITEMS + NT - 1) / NT;               // item steps of the B stage
+    constexpr int RPS = FORM == 0 ? NT / IPR_B : 0;           // FORM 0: B rows per item step (8 / 4), whole rows per wave
+    // row pitch of the B stage: 16 mod 32 doubles, so that the four k rows of a fragment read fall on different banks
+    constexpr int SB = FORM == 0 ? 144 : 16 * T + ((T & 1) ? 32 : 16);
+    constexpr int A_STAGE = NA * RA * SA, B_STAGE = KT * SB;
+    static_assert(FORM == 1 || (NT % IPR_B == 0 && KT % RPS == 0), "FORM 0: item steps cover whole B rows");
+    using Item = FastItem<VEC>;
+    using item_t = typename Item::type;
+
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    double* As = smem;
+    double* Bs = smem + 2 * A_STAGE;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int nk = g.nk;
+    const unsigned P = gridDim.x;
+    const int k_tail = g.k - (nk - 1) * KT;                   // valid k of a tile's last stage (1 ... 16)
+
+    if (g.stagger_slots > 1) {      // (wave-uniform; a bounded loop: every wave leaves it)
+        const int steps = (int)((blockIdx.x >> 3) % (unsigned)g.stagger_slots);
+        const int64_t until = (int64_t)__builtin_amdgcn_s_memtime() + (int64_t)steps * g.stagger_cycles;
+        for (int i = 0; i < 4096 && (int64_t)__builtin_amdgcn_s_memtime() < until; ++i) __builtin_amdgcn_s_sleep(64);
+    }
+
+    // ---- fetch cursor
+    uint64_t a_ptr[NA];
+    uint64_t b_ptr[FORM == 0 ? NB : 1];
+    unsigned voff_b[FORM == 0 ? 1 : NB];
+    unsigned f_v = blockIdx.x;
+    int f_k = 0;
+    bool f_valid = true;
+    const unsigned voff_a = (unsigned)(tid / IPR_A) * (unsigned)g.lda * 8u + (unsigned)(tid % IPR_A) * IB;
+    // start of tile w of the big extent
+    auto tile_start = [&](unsigned v) -> int64_t {
+        const unsigned w = xcd_chunked_index_fast(v, g.total);
+        return (int64_t)__builtin_amdgcn_readfirstlane((int)w) * 128;
+    };
+    auto aim = [&](unsigned v) {
+        const int64_t t0 = tile_start(v);
+        if constexpr (FORM == 0) {
+            // virtual column j -> element (j / W) * sb + j % W of its B row; the tile's first segment goes into the scalar base
+            // (32-bit divisions: the host admits big + 256 < 2^32 only)
+            const unsigned W = (unsigned)g.Wp;
+            const unsigned seg0 = __builtin_amdgcn_readfirstlane((unsigned)t0 / W);
+            const unsigned j = (unsigned)t0 + (unsigned)(tid % IPR_B) * EPI;
+            const unsigned sj = j / W;
+            voff_b[0] = (unsigned)(((int64_t)(sj - seg0) * g.sb + (j - sj * W)) * 8);
+            const char* Bb = reinterpret_cast<const char*>(g.B + (int64_t)seg0 * g.sb);
+#pragma unroll
+            for (int i = 0; i < NB; ++i)
+                b_ptr[i] = uniform64(reinterpret_cast<uint64_t>(Bb + (size_t)(wave * 64 / IPR_B + i * RPS) * g.ldb * 8));
+#pragma unroll
+            for (int i = 0; i < NA; ++i)
+                a_ptr[i] = uniform64(reinterpret_cast<uint64_t>(reinterpret_cast<const char*>(g.A) + (size_t)i * RA * g.lda * 8));
+        } else {
+#pragma unroll
+            for (int i = 0; i < NA; ++i)
+                a_ptr[i] = uniform64(reinterpret_cast<uint64_t>(reinterpret_cast<const char*>(g.A) + (size_t)(t0 + i * RA) * g.lda * 8));
+            b_ptr[0] = uniform64(reinterpret_cast<uint64_t>(g.B));
+        }
+    };
+    // FORM 1: the B stage (a 16 x 16 T piece of the coefficient matrix) as a flat item list; threads beyond it are parked on
+    // the pad columns of LDS row 0 and on an offset past the end of the (small) matrix
+    unsigned st_b_off[FORM == 0 ? 1 : NB];
+    if constexpr (FORM == 0) {
+        st_b_off[0] = (unsigned)((tid / IPR_B) * SB + (tid % IPR_B) * EPI);
+    } else {
+#pragma unroll
+        for (int i = 0; i < NB; ++i) {
+            const int idx = tid + NT * i;
+            const bool ok = idx < B_ITEMS;
+            voff_b[i] = ok ? (unsigned)(idx / IPR_B) * (unsigned)g.ldb * 8u + (unsigned)(idx % IPR_B) * IB : 0x7FFFFFF0u;
+            st_b_off[i] = ok ? (unsigned)((idx / IPR_B) * SB + (idx % IPR_B) * EPI) : (unsigned)(16 * T + 2 * (tid & 7));
+        }
+    }
+    aim(f_v);
+    const size_t a_step = KT * 8;
+    const size_t b_step = (size_t)KT * g.ldb * 8;
+
+    double* st_a = As + (tid / IPR_A) * SA + (tid % IPR_A) * EPI;
+    const double* rd_a = FORM == 0 ? As + (lane & 15) * SA + (lane >> 4)
+                                   : As + (wave * 16 + (lane & 15)) * SA + (lane >> 4);
+    const double* rd_b = FORM == 0 ? Bs + (lane >> 4) * SB + wave * 16 + (lane & 15)
+                                   : Bs + (lane >> 4) * SB + (lane & 15);
+
+    item_t ra[SETS][NA], rb[SETS][NB];
+
+    // Loads are issued UNCONDITIONALLY (a cursor that has run out of tiles loads with a zero range: the descriptor returns
+    // zeros without touching memory), and so is the write of the next stage to LDS: with a load count that does not depend on
+    // the path the compiler waits for exactly the loads a stage needs (vmcnt(n) with the newer register set still in flight)
+    // instead of draining to the newest one -- the second stage of lookahead is real.
+    auto fetch = [&](auto set_c) {
+        constexpr int set = decltype(set_c)::value;
+#ifdef QS_STRIP_ABLATE_LOADS      // development: no memory traffic on the load side (zero range: the descriptor answers with zeros)
+        const unsigned live = 0u;
+#else
+        const unsigned live = f_valid ? 0xFFFFFFFFu : 0u;
+#endif
+#pragma unroll
+        for (int i = 0; i < NA; ++i) {
+#ifdef QS_STRIP_ABLATE_LOADS_A
+            ra[set][i] = Item::load(a_ptr[i], 0u, voff_a);
+#else
+            ra[set][i] = Item::load(a_ptr[i], bytes_left(g.a_end, a_ptr[i]) & live, voff_a);
+#endif
+            a_ptr[i] += a_step;
+        }
+        if constexpr (FORM == 0) {
+#pragma unroll
+            for (int i = 0; i < NB; ++i) {
+#ifdef QS_STRIP_ABLATE_LOADS_B
+                rb[set][i] = Item::load(b_ptr[i], 0u, voff_b[0]);
+#else
+                rb[set][i] = Item::load(b_ptr[i], bytes_left(g.b_end, b_ptr[i]) & live, voff_b[0]);
+#endif
+                b_ptr[i] += b_step;
+            }
+        } else {
+            const unsigned room = bytes_left(g.b_end, b_ptr[0]) & live;
+#pragma unroll
+            for (int i = 0; i < NB; ++i) rb[set][i] = Item::load(b_ptr[0], room, voff_b[i]);
+            b_ptr[0] += b_step;
+        }
+        if (f_valid && ++f_k == nk) {
+            f_k = 0;
+            f_v += P;
+            f_valid = f_v < g.total;
+            if (f_valid) aim(f_v);
+        }
+    };
+
+    int s_k = 0;
+    auto stash = [&](auto buf_c, auto set_c) {
+        constexpr int buf = decltype(buf_c)::value;
+        constexpr int set = decltype(set_c)::value;
+        __builtin_amdgcn_sched_barrier(0);
+        const bool tail = (s_k == nk - 1) && (k_tail < KT);
+        if (++s_k == nk) s_k = 0;
+        if (tail) {      // last k-stage of a tile with a K tail: zero the k >= K part of both operands
+            const item_t zero = item_t(0.0);
+#pragma unroll
+            for (int i = 0; i < NA; ++i) {
+                if constexpr (VEC) {
+                    if ((tid % IPR_A) * 2 >= k_tail) ra[set][i][0] = 0.0;
+                    if ((tid % IPR_A) * 2 + 1 >= k_tail) ra[set][i][1] = 0.0;
+                } else {
+                    if ((tid % IPR_A) >= k_tail) ra[set][i] = zero;
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < NB; ++i) {
+                const int row = FORM == 0 ? tid / IPR_B + i * RPS : (tid + NT * i) / IPR_B;
+                if (row >= k_tail) rb[set][i] = zero;
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < NA; ++i) {
+            double* d = st_a + buf * A_STAGE + i * RA * SA;
+            if constexpr (VEC) *reinterpret_cast<f64x2*>(d) = ra[set][i];
+            else d[0] = ra[set][i];
+        }
+#pragma unroll
+        for (int i = 0; i < NB; ++i) {
+            double* d = Bs + buf * B_STAGE + (FORM == 0 ? st_b_off[0] + i * RPS * SB : st_b_off[i]);
+            if constexpr (VEC) *reinterpret_cast<f64x2*>(d) = rb[set][i];
+            else d[0] = rb[set][i];
+        }
+    };
+
+    f64x4 acc[T];
+
+    // fragments of k-step kk: the T shared ones (`sf`) and the wave's own (`of`)
+    auto read_frags = [&](auto buf_c, int kk, double (&sf)[T], double& of) {
+        constexpr int buf = decltype(buf_c)::value;
+        const double* as = rd_a + buf * A_STAGE;
+        const double* bs = rd_b + buf * B_STAGE;
+        if constexpr (FORM == 0) {
+#pragma unroll
+            for (int i = 0; i < T; ++i) sf[i] = as[i * 16 * SA + kk * 4];
+            of = bs[kk * 4 * SB];
+        } else {
+            of = as[kk * 4];
+#pragma unroll
+            for (int j = 0; j < T; ++j) sf[j] = bs[kk * 4 * SB + j * 16];
+        }
+    };
+    auto mfma_step = [&](const double (&sf)[T], const double of, auto fresh_c) {
+        constexpr bool fresh = decltype(fresh_c)::value;
+        const f64x4 zero = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int i = 0; i < T; ++i) {
+            if constexpr (FORM == 0) acc[i] = __builtin_amdgcn_mfma_f64_16x16x4f64(sf[i], of, fresh ? zero : acc[i], 0, 0, 0);
+            else acc[i] = __builtin_amdgcn_mfma_f64_16x16x4f64(of, sf[i], fresh ? zero : acc[i], 0, 0, 0);
+        }
+    };
+
+    // register r of a lane holds row (lane >> 4) + 4 r, column lane & 15 of a 16 x 16 block: a store instruction writes four
+    // rows of 128 contiguous bytes
+    auto epilogue = [&](unsigned v) __attribute__((always_inline)) {
+        const int64_t t0 = tile_start(v);
+        if constexpr (FORM == 0) {
+            const unsigned W = (unsigned)g.Wp;
+            const unsigned j = (unsigned)t0 + wave * 16 + (lane & 15);
+            const unsigned sj = j / W;
+#ifdef QS_STRIP_ABLATE_STORES_LOCAL      // development: every tile stores to the same few rows (the store instructions without their memory traffic)
+            double* __restrict__ C = g.C + (j & 127) + (int64_t)(lane >> 4) * g.ldc + (blockIdx.x & 255) * 128;
+#else
+            double* __restrict__ C = g.C + (int64_t)sj * g.sc + (j - sj * W) + (int64_t)(lane >> 4) * g.ldc;
+#endif
+#ifdef QS_STRIP_ABLATE_STORES     // development: no stores (the condition keeps the products alive)
+            const bool col_ok = acc[0][0] == 1.2345e300;
+#else
+            const bool col_ok = j < (unsigned)g.big && j - sj * W < (unsigned)g.W;
+#endif
+#pragma unroll
+            for (int i = 0; i < T; ++i) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int row = i * 16 + 4 * r + (lane >> 4);
+                    if (col_ok && (i < T - 1 || row < g.small))
+#ifdef QS_STRIP_ABLATE_STORES_LOCAL
+                        __builtin_nontemporal_store(acc[i][r], C + (int64_t)(4 * r) * g.ldc);
+#else
+                        __builtin_nontemporal_store(acc[i][r], C + (int64_t)(i * 16 + 4 * r) * g.ldc);
+#endif
+                }
+            }
+        } else {
+            const int64_t row0 = t0 + wave * 16 + (lane >> 4);
+            double* __restrict__ C = g.C + row0 * g.ldc + (lane & 15);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+#ifdef QS_STRIP_ABLATE_STORES
+                const bool row_ok = acc[0][0] == 1.2345e300;
+#else
+                const bool row_ok = row0 + 4 * r < g.big;
+#endif
+#pragma unroll
+                for (int jb = 0; jb < T; ++jb) {
+                    if (row_ok && (jb < T - 1 || jb * 16 + (lane & 15) < g.small))
+                        __builtin_nontemporal_store(acc[jb][r], C + (int64_t)(4 * r) * g.ldc + jb * 16);
+                }
+            }
+        }
+    };
+
+    using B0 = std::integral_constant<int, 0>;
+    using B1 = std::integral_constant<int, 1>;
+    using T_ = std::true_type;
+    using F_ = std::false_type;
+    using S1 = std::integral_constant<int, SETS == 2 ? 1 : 0>;      // register set of the odd stages
+
+    const unsigned my_tiles = (g.total - blockIdx.x + P - 1) / P;
+    const int stages = (int)my_tiles * nk;      // (the host keeps tiles x stages below 2^31)
+
+    fetch(B0{});                       // global stage 0
+    stash(B0{}, B0{});
+    __syncthreads();
+    double s0[T], s1[T], o0, o1;
+    fetch(S1{});                       // stage 1
+    if constexpr (SETS == 2) fetch(B0{});      // stage 2
+    read_frags(B0{}, 0, s0, o0);
+
+    unsigned c_v = blockIdx.x;
+    int c_k = 0;
+
+    // One global stage.  The LDS buffer the next stage goes into was last read before the PREVIOUS barrier, so it is free
+    // from the start of this stage: the next stage is written (and the registers it leaves refilled from memory) right
+    // after the first block of MFMAs, two blocks ahead of the barrier -- with one workgroup per CU nothing else would cover
+    // the latency of those LDS writes (both waves of a SIMD reach the barrier together).
+    auto stage = [&](auto cur_c, int gs) {
+        constexpr int cur = decltype(cur_c)::value;
+        using NXT = std::integral_constant<int, cur ^ 1>;
+        using NSET = std::integral_constant<int, SETS == 2 ? (cur ^ 1) : 0>;
+        const bool has_next = gs + 1 < stages;
+        const int ks_live = (c_k == nk - 1) ? (k_tail + 3) / 4 : KS;
+        read_frags(cur_c, 1, s1, o1);
+        __builtin_amdgcn_sched_barrier(0);
+        if (c_k == 0) mfma_step(s0, o0, T_{}); else mfma_step(s0, o0, F_{});
+        __builtin_amdgcn_sched_barrier(0);
+        stash(NXT{}, NSET{});                    // stage gs + 1 (behind the last stage: zeros, never read)
+        __builtin_amdgcn_sched_barrier(0);
+        fetch(NSET{});                           // stage gs + 3 (two register sets) / gs + 2 (one)
+        __builtin_amdgcn_sched_barrier(0);
+        read_frags(cur_c, 2, s0, o0);
+        __builtin_amdgcn_sched_barrier(0);
+        if (1 < ks_live) mfma_step(s1, o1, F_{});
+        __builtin_amdgcn_sched_barrier(0);
+        read_frags(cur_c, 3, s1, o1);
+        __builtin_amdgcn_sched_barrier(0);
+        if (2 < ks_live) mfma_step(s0, o0, F_{});
+        __builtin_amdgcn_sched_barrier(0);
+#ifndef QS_STRIP_ABLATE_BARRIER   // development: no stage barrier (results wrong; what the barrier costs)
+        __syncthreads();
+#endif
+        if (has_next) read_frags(NXT{}, 0, s0, o0);
+        __builtin_amdgcn_sched_barrier(0);
+        if (3 < ks_live) mfma_step(s1, o1, F_{});
+        __builtin_amdgcn_sched_barrier(0);
+        if (++c_k == nk) {
+            epilogue(c_v);
+            c_k = 0;
+            c_v += P;
+        }
+    };
+
+    for (int gs = 0; gs < stages; gs += 2) {
+        stage(B0{}, gs);
+        if (gs + 1 < stages) stage(B1{}, gs + 1);
+    }
+}
+
+namespace {
+
+// relative rate of a strip tile against the 128 x 128 tile of qs_gemm_fast.hip (same units as its shape weights)
+inline double strip_weight(int t, bool vec) {
+    if (g_tune.gemm_strip_w > 0) return 0.01 * g_tune.gemm_strip_w;
+    // (same-box sweep, profiles/r04_strip_sweep.txt: at equal tile extents -- l = 120, T = 8 -- the strip tile runs at 0.99 of
+    // the 128 x 128 edge-form tile)
+    return (t >= 8 ? 1.0 : t >= 5 ? 0.95 : 0.80) * (vec ? 1.0 : 0.88);
+}
+
+template <int FORM, int T, bool VEC>
+int launch_strip(const StripArgs& g, hipStream_t stream) {
+    constexpr int SETS = T <= 12 ? 2 : 1;
+    constexpr int EPI = VEC ? 2 : 1;
+    constexpr int RA = 512 / (16 / EPI);
+    constexpr int A_ROWS = FORM == 0 ? 16 * T : 128;
+    constexpr int NA = (A_ROWS + RA - 1) / RA;
+    constexpr int SB = FORM == 0 ? 144 : 16 * T + ((T & 1) ? 32 : 16);
+    const size_t lds = sizeof(double) * 2 * (size_t)(NA * RA * 18 + 16 * SB);
+    int64_t P = device_cu_count();
+    P -= P % 8;
+    if (P < 8) P = 8;
+    if (P > (int64_t)g.total) P = g.total;
+    auto kern = gemm_strip_kernel<FORM, T, VEC, SETS>;
+    static PerDeviceLds lds_opt_in;
+    if (int rc = opt_in_dynamic_lds((const void*)kern, lds, lds_opt_in, "hipFuncSetAttribute(gemm_strip)")) return rc;
+    hipLaunchKernelGGL(kern, dim3((unsigned)P), dim3(512), lds, stream, g);
+    note_dispatch("qs::gemm_strip_kernel<%d, %d, %s, %d>", FORM, T, VEC ? "true" : "false", SETS);
+    return launch_status("gemm_strip launch");
+}
+
+template <int FORM, bool VEC>
+int launch_strip_t(int t, const StripArgs& g, hipStream_t stream) {
+    switch (t) {
+#ifdef QS_DEV_FEW_SHAPES      // development / sanitizer builds of the HOST side
+        case 9: return launch_strip<FORM, 9, VEC>(g, stream);
+#else
+#define QS_STRIP(TT) case TT: return launch_strip<FORM, TT, VEC>(g, stream);
+        QS_STRIP(1) QS_STRIP(2) QS_STRIP(3) QS_STRIP(4) QS_STRIP(5) QS_STRIP(6) QS_STRIP(7) QS_STRIP(8)
+        QS_STRIP(9) QS_STRIP(10) QS_STRIP(11) QS_STRIP(12) QS_STRIP(13) QS_STRIP(14) QS_STRIP(15) QS_STRIP(16)
+#undef QS_STRIP
+#endif
+        default: return 1;
+    }
+}
+
+}  // namespace
+
+// QS_OK after launching, 1 = not eligible / not the cheapest (the caller goes on to the other kernels).
+// other_cost: the best estimate of the other tiled kernels for this product, in the units of qs_gemm_fast.hip (tiles x tile
+// area / relative rate over two workgroups per CU).
+int gemm_strip_try(int dtype, const double* A, const double* B, double* C, int64_t m, int64_t n, int64_t k, int64_t lda,
+                   int64_t ldb, int64_t ldc, int64_t batch, int64_t sa, int64_t sb, int64_t sc, int accumulate,
+                   double other_cost, hipStream_t stream) {
+    if (!g_tune.gemm_strip || dtype != QS_F64 || accumulate) return 1;
+    if (m <= 0 || n <= 0 || k <= 0 || batch <= 0 || k >= (int64_t(1) << 30)) return 1;
+    // which extent is the small one: A shared by the batch and m <= 256 -> tall tiles over virtual columns; otherwise one
+    // product with n <= 256 -> wide tiles over the rows
+    int form;
+    if ((batch == 1 || sa == 0) && m <= 256 && (batch > 1 || n >= m)) form = 0;
+    else if (batch == 1 && n <= 256) form = 1;
+    else return 1;
+    if (batch == 1) { sb = 0; sc = 0; }
+    StripArgs g;
+    g.A = A; g.B = B; g.C = C;
+    g.lda = lda; g.ldb = ldb; g.ldc = ldc;
+    g.sb = sb; g.sc = sc;
+    g.k = (int)k; g.nk = (int)cdiv(k, 16);
+    int t;
+    if (form == 0) {
+        // Lane offsets are 32-bit and unsigned: a tile's columns reach at most 128 / n + 1 segments past its first one.  (Columns
+        // past the last one of the last tile compute offsets of their own -- whatever they address is either inside the
+        // operand or cut off by the range check of the buffer descriptor, and they are never stored.)
+        if (sb < 0 || sc < 0 || lda < k || ldb < n || ldc < n) return 1;
+        if ((128 / n + 2) * sb * 8 + n * 8 >= (int64_t(1) << 32) - 65536 || 64 * lda * 8 >= (int64_t(1) << 31)) return 1;
+        g.W = n; g.Wp = n + (n & 1);
+        if (g.Wp * batch + 256 >= (int64_t(1) << 32)) return 1;      // the kernel's column arithmetic is 32-bit
+        g.big = g.Wp * batch; g.small = (int)m;
+        t = (int)cdiv(m, 16);
+    } else {
+        if (lda < k || ldb < n || ldc < n) return 1;
+        if (64 * lda * 8 >= (int64_t(1) << 31) || 16 * ldb * 8 + 4096 >= (int64_t(1) << 30)) return 1;
+        g.big = m; g.W = g.Wp = 0; g.small = (int)n;
+        t = (int)cdiv(n, 16);
+    }
+    const int64_t tiles = cdiv(g.big, 128);
+    if (tiles * cdiv(k, 16) >= (int64_t(1) << 31)) return 1;
+    {   // stagger of the workgroups' starts (experiment: QS_STRIP_STAGGER = slots, 0 / unset = off)
+        static const int slots = [] { const char* e = getenv("QS_STRIP_STAGGER"); return e ? atoi(e) : 0; }();
+        g.stagger_slots = slots;
+        // one tile = nk stages x 4 k-steps x t products x 64 cycles x two waves per SIMD, at ~0.75 of the matrix rate
+        g.stagger_cycles = slots > 1 ? (int)(cdiv(k, 16) * 4 * t * 64 * 2 * 4 / 3 / slots) : 0;
+    }
+    g.total = (unsigned)tiles;
+    g.a_end = reinterpret_cast<uint64_t>(A) + (uint64_t)(((m - 1) * lda + k) * 8);
+    g.b_end = reinterpret_cast<uint64_t>(B) + (uint64_t)(((batch - 1) * sb + (k - 1) * ldb + n) * 8);
+#ifdef QS_STRIP_ITEMS8
+    const bool vec = aligned(A, 16) && aligned(B, 16) && !(lda & 1) && !(ldb & 1) && !(sb & 1) && !(n & 1) && !(k & 1);
+#else
+    const bool vec = true;
+#endif
+    if (g_tune.gemm_strip == 1) {
+        // estimated time: rounds of the tile list over the CUs (one eight-wave workgroup each = both slots of the other
+        // kernels' two four-wave workgroups) x tile area / relative rate
+        const double slots = device_cu_count();
+        const double rounds = tiles > 8 * slots ? tiles / slots : ceil(tiles / slots);
+        const double cost = rounds * (16.0 * t) * 128.0 / 2.0 / strip_weight(t, vec);
+        if (!(cost < other_cost)) return 1;
+    }
+#ifdef QS_STRIP_ITEMS8
+    if (!vec) { g.Wp = g.W; g.big = form == 0 ? n * batch : m; g.total = (unsigned)cdiv(g.big, 128); }
+    if (!vec) return form == 0 ? launch_strip_t<0, false>(t, g, stream) : launch_strip_t<1, false>(t, g, stream);
+#endif
+    return form == 0 ? launch_strip_t<0, true>(t, g, stream) : launch_strip_t<1, true>(t, g, stream);
+}
+
+}  // namespace qs

@@ -605,6 +605,128 @@ def test_fitted_tile_shapes_vs_oracle(K, m, n, k, batch):
         K.tuning_reset()
 
 
+@pytest.mark.parametrize("m,n,k,batch", [
+    (130, 130, 130, 40),       # contraction c of l = 130: a batch of narrow products tiles as one long row of virtual columns
+    (100, 10000, 100, 1),      # contraction a-like: one product, a huge column extent
+    (144, 144 * 144, 144, 3),  # contraction b-like, whole blocks of 16
+    (129, 129, 129, 17), (97, 97 * 5, 97, 7),       # odd sizes: 8-byte items
+    (253, 600, 253, 2), (256, 384, 256, 2),         # sixteen row blocks (one register set)
+    (20, 300, 20, 5), (1, 7, 1, 3), (17, 33, 5, 2),
+    (70000, 130, 130, 1),      # contraction d: the rows of the tensor against the coefficient matrix (wide tiles)
+    (4097, 100, 100, 1), (2000, 97, 97, 1), (1500, 253, 253, 1), (1000, 256, 256, 1), (300, 7, 3, 1), (129, 16, 4, 1),
+])
+def test_strip_kernels_vs_oracle_and_bit_identical_to_the_general_kernel(K, m, n, k, batch):
+    # round 4: the small extent of a product covered by ONE tile to the next multiple of 16, eight waves per workgroup
+    # (qs_gemm_strip.hip): tall tiles over virtual columns when the left operand is shared and small, wide tiles over the
+    # rows when the right one is
+    rng = np.random.default_rng(m + 3 * n + 5 * k + batch)
+    A = rng.standard_normal((m, k))
+    B = rng.standard_normal((batch, k, n)) if batch > 1 else rng.standard_normal((k, n))
+    ref = np.matmul(A, B)
+    try:
+        K.tuning_set("gemm_fast", 0)
+        K.tuning_set("gemm_fit", 0)
+        K.tuning_set("gemm_strip", 0)
+        K.tuning_set("gemm_stream", 0)
+        K.tuning_set("gemm_skinny", 0)
+        general = host(K.matmul(dev(A), dev(B)))
+        assert "gemm_kernel<2, 2" in K.last_dispatch(), K.last_dispatch()
+        K.tuning_set("gemm_strip", 2)
+        got = host(K.matmul(dev(A), dev(B)))
+        ran = K.last_dispatch()
+        assert "gemm_strip_kernel<" in ran, ran
+        assert relerr(got, ref) <= 1e-13
+        assert np.array_equal(got, general)                # the same k-ordered sums: identical bits
+    finally:
+        K.tuning_reset()
+
+
+def test_strip_kernels_keep_non_finite_values_in_their_rows_and_columns(K):
+    # rows / columns beyond the small extent and k >= K multiply whatever the loads returned: nothing of it may reach a
+    # stored element (selects on the K tail, never-stored blocks elsewhere)
+    rng = np.random.default_rng(78)
+    try:
+        K.tuning_set("gemm_strip", 2)
+        K.tuning_set("gemm_stream", 0)
+        K.tuning_set("gemm_skinny", 0)
+        for (m, n, k, batch) in [(70, 58, 21, 3), (3000, 58, 21, 1)]:
+            A = rng.standard_normal((m, k))               # lda == k: the tail of row i is the head of row i + 1
+            B = rng.standard_normal((batch, k, n)) if batch > 1 else rng.standard_normal((k, n))
+            A[31, 0] = np.nan
+            A[40, 3] = np.inf
+            B[..., 2, 57] = np.nan
+            B[..., 20, 0] = np.inf
+            with np.errstate(invalid="ignore"):
+                ref = np.matmul(A, B)
+            got = host(K.matmul(dev(A), dev(B)))
+            assert "gemm_strip_kernel<" in K.last_dispatch()
+            assert np.array_equal(np.isnan(got), np.isnan(ref))
+            ok = np.isfinite(ref)
+            np.testing.assert_allclose(got[ok], ref[ok], rtol=1e-12, atol=1e-12)
+    finally:
+        K.tuning_reset()
+
+
+@pytest.mark.parametrize("L,M", [(100, 100), (129, 129), (130, 130), (97, 113), (144, 120), (150, 150), (84, 81)])
+def test_transform_on_the_strip_kernels_equals_the_general_kernel_and_the_oracle(K, L, M):
+    rng = np.random.default_rng(L * 7 + M)
+    u = rng.standard_normal((L, L, L, L)) if L <= 100 else None
+    g = torch.Generator(device="cuda:0").manual_seed(L)
+    ud = dev(u) if u is not None else torch.rand(L, L, L, L, dtype=torch.float64, device="cuda:0", generator=g)
+    C = torch.randn(L, M, dtype=torch.float64, device="cuda:0", generator=g) / L**0.5
+    Ct = torch.randn(M, L, dtype=torch.float64, device="cuda:0", generator=g) / L**0.5
+    try:
+        K.tuning_set("gemm_fast", 0)
+        K.tuning_set("gemm_fit", 0)
+        K.tuning_set("gemm_strip", 0)
+        K.tuning_set("quad4s", 0)
+        gen = K.transform_two_body(ud, C, Ct)
+        assert "gemm_strip" not in K.last_dispatch()
+        K.tuning_set("gemm_strip", 2)
+        got = K.transform_two_body(ud, C, Ct)
+        ran = K.last_dispatch()
+        assert "gemm_strip_kernel<1, " in ran and "gemm_strip_kernel<0, " in ran and "gemm_kernel" not in ran and "gemm_fast" not in ran, ran
+        assert torch.equal(got, gen)
+        K.tuning_reset()
+        auto = K.transform_two_body(ud, C, Ct)              # whatever the automatic choice is: the same bits
+        assert torch.equal(auto, gen)
+    finally:
+        K.tuning_reset()
+    if u is not None:
+        ref = orc.transform_two_body(u, host(C), host(Ct))
+        assert relerr(host(got), ref) <= 1e-12
+    x, y, z, w = (torch.randn(n_, dtype=torch.float64, device="cuda:0", generator=g) for n_ in (M, M, M, M))
+    lhs = torch.einsum("pqrs,p,q,r,s->", got, x, y, z, w)
+    rhs = torch.einsum("abcd,a,b,c,d->", ud, Ct.T @ x, Ct.T @ y, C @ z, C @ w)
+    assert abs(lhs - rhs).item() <= 1e-10 * abs(rhs).item()
+
+
+@pytest.mark.parametrize("m,n,k,batch", [(253, 300, 253, 2), (129, 129, 129, 5), (1000, 97, 97, 1), (255, 255, 255, 1), (131, 77, 35, 3)])
+def test_edge_form_with_16_byte_items_at_odd_strides_is_bit_identical(K, m, n, k, batch):
+    # round 4: gfx950 carries out 16-byte buffer loads and stores at any 8-byte-aligned address, so the VALU-free kernel's edge
+    # form stages odd sizes with 16-byte items too (tuning key gemm_fast_unaligned = 0: the 8-byte items of rounds 1-3)
+    rng = np.random.default_rng(m + n + k)
+    A = rng.standard_normal((m, k))
+    B = rng.standard_normal((batch, k, n))
+    ref = np.matmul(A, B)
+    try:
+        K.tuning_set("gemm_strip", 0)
+        K.tuning_set("gemm_fast", 3)
+        K.tuning_set("gemm_fast_unaligned", 0)
+        old = host(K.matmul(dev(A), dev(B)))
+        assert ", false, true>" in K.last_dispatch(), K.last_dispatch()
+        K.tuning_set("gemm_fast_unaligned", 1)
+        got = host(K.matmul(dev(A), dev(B)))
+        assert ", true, true>" in K.last_dispatch(), K.last_dispatch()
+        assert relerr(got, ref) <= 1e-13
+        assert np.array_equal(got, old)
+        out = dev(ref.copy())
+        K.matmul(dev(A), dev(B), out=out, accumulate=True)
+        assert relerr(host(out), 2 * ref) <= 1e-13
+    finally:
+        K.tuning_reset()
+
+
 def test_edge_form_keeps_non_finite_values_in_their_rows(K):
     # the K tail is removed with selects, not by multiplying with zero: a NaN/Inf in one row of A
     # (or one column of B) must not reach any other row (column) of the product

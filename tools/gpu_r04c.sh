@@ -1,0 +1,12 @@
+set -o pipefail
+mkdir -p gpurun_out/r04c
+export TMPDIR=/tmp
+timeout -k 10 900 python -m pytest tests/test_gpu_kernels.py -x -q -k "strip or 16_byte_items" > gpurun_out/r04c/tests.log 2>&1; rc=$?; echo "tests rc=$rc"; tail -30 gpurun_out/r04c/tests.log | cut -c1-250
+[ $rc -ne 0 ] && exit 0
+export QS_SWEEP_DTYPES=f64
+export QS_SWEEP_L=97,100,105,112,113,120,127,129,130,136,144,150,153,160,171,176,190,193,200,208,210,224,231,240,253,255
+for cfg in "gemm_strip=0,gemm_fast_unaligned=0" "gemm_strip=0,gemm_fast_unaligned=1" "gemm_strip=2" "gemm_strip=1"; do
+  echo "# QS_SWEEP_TUNE=$cfg" >> gpurun_out/r04c/sweep.txt
+  QS_SWEEP_TUNE=$cfg timeout -k 10 600 python tools/size_sweep.py >> gpurun_out/r04c/sweep.txt 2>&1 || { echo "sweep $cfg failed"; tail -5 gpurun_out/r04c/sweep.txt; }
+done
+cat gpurun_out/r04c/sweep.txt | cut -c1-150

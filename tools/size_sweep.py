@@ -16,7 +16,8 @@ for kv in os.environ.get("QS_SWEEP_TUNE", "").split(","):          # e.g. QS_SWE
     if "=" in kv:
         K.tuning_set(kv.split("=")[0], int(kv.split("=")[1]))
 print("l dtype us TFLOP/s kernels")
-for cx in (False, True):
+dtypes = [d == "c128" for d in os.environ.get("QS_SWEEP_DTYPES", "f64,c128").split(",")]
+for cx in dtypes:
     for l in sizes:
         if cx and l > 224:
             continue
