@@ -700,6 +700,8 @@ def bandwidth_workload(args, torch, dist, kernels, sharded, device, rank, world,
 # ----------------------------------------------------------------------------------------------
 
 def run_rank(args):
+    if os.environ.get("QS_BENCH_HANG_LEG") and os.environ.get("QS_BENCH_HANG_LEG") == os.environ.get("QS_BENCH_LEG"):
+        time.sleep(3600)      # test hook (tests/test_gpu_bench_script.py): a leg that hangs before it has touched the GPU
     import torch
     import torch.distributed as dist
 

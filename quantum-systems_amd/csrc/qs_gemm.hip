@@ -505,7 +505,9 @@ int gemm_f64(const double* A, const double* B, double* C, int64_t m, int64_t n, 
                 if (g_tune.gemm_fit == 2 || fcost < cost) { fit_cfg = fc; cost = fcost; }
             }
         }
-        {   // strip kernels (qs_gemm_strip.hip): the small extent of the product covered by one tile to the next multiple of 16
+        if (g_tune.gemm_strip == 2 || g_tune.gemm_fast == 1) {
+            // strip kernels (qs_gemm_strip.hip): the small extent of the product covered by one tile to the next multiple of 16
+            // (not when a tuning key forces one of the other tiled kernels)
             const bool even = vec && aligned(C, 16) && !(ldc & 1) && !(sc & 1);
             const double fast = gemm_fast_estimate(QS_F64, m, n, k, batch, even);
             const double gen = cost / kGeneralRelativeRate;

@@ -35,44 +35,51 @@
 
 namespace qs {
 
+typedef unsigned u32x2_t __attribute__((ext_vector_type(2)));
+
 struct StripArgs {
     const double* A;
     const double* B;
     double* C;
     int64_t lda, ldb, ldc;   // elements
     int64_t sb, sc;          // FORM 0: distance between the column segments (batch entries) of B and of C
-    uint64_t a_end, b_end;   // one past the last byte of each operand
-    int64_t big;             // FORM 0: virtual columns (segments x W);  FORM 1: rows m
+    uint64_t a_end, b_end, c_end;   // one past the last byte of each operand
+    int64_t big;             // FORM 0: virtual columns (segments x Wp);  FORM 1: rows m
     int64_t W;               // FORM 0: columns per segment
     int64_t Wp;              // FORM 0: W rounded up to even: the width of a segment in VIRTUAL columns -- an odd segment gets one
                              // dummy column at its end, so that a 16-byte item (two adjacent columns) never straddles two segments
     int small;               // FORM 0: rows m (of A and of the result);  FORM 1: columns n
     int k, nk;               // K, ceil(K / 16)
     unsigned total;          // tiles
-    int stagger_slots;       // > 1: workgroup b starts (b / 8) % slots phase steps late, so that the epilogues of the CUs --
-    int stagger_cycles;      // 147 KB of stores each, every tile -- do not reach memory chip-wide at the same moment (cycles per step)
 };
 
-template <int FORM, int T, bool VEC, int SETS>
+// T = blocks of 16 along the small extent (shared fragments), WN = blocks of 16 per wave along the big extent (tile = 128 WN
+// of it), SETS = register sets of global data in flight (2: two stages of lookahead).
+template <int FORM, int T, int WN, int SETS>
 __global__ __launch_bounds__(512, 1)
 void gemm_strip_kernel(const StripArgs g) {
     constexpr int KT = 16, KS = 4, NT = 512, SA = KT + 2;
-    constexpr int EPI = VEC ? 2 : 1;                          // tensor elements per global item
-    constexpr unsigned IB = 8u * EPI;                         // bytes per item
-    constexpr int IPR_A = KT / EPI;                           // items per A row of a stage
-    constexpr int RA = NT / IPR_A;                            // A rows covered by one item step (64 / 32)
-    constexpr int A_ROWS = FORM == 0 ? 16 * T : 128;
+    constexpr unsigned IB = 16;                               // bytes per global item (two elements)
+    constexpr int IPR_A = KT / 2;                             // items per A row of a stage
+    constexpr int RA = NT / IPR_A;                            // A rows covered by one item step (64)
+    constexpr int TILE = 128 * WN;                            // extent of a tile along the big extent
+    constexpr int A_ROWS = FORM == 0 ? 16 * T : TILE;
     constexpr int NA = (A_ROWS + RA - 1) / RA;                // item steps of the A stage
-    constexpr int B_COLS = FORM == 0 ? 128 : 16 * T;
-    constexpr int IPR_B = B_COLS / EPI;                       // items per B row
+    constexpr int B_COLS = FORM == 0 ? TILE : 16 * T;
+    constexpr int IPR_B = B_COLS / 2;                         // items per B row
     constexpr int B_ITEMS = KT * IPR_B;
     constexpr int NB = (B_ITEMS + NT - 1) / NT;               // item steps of the B stage
-    constexpr int RPS = FORM == 0 ? NT / IPR_B : 0;           // FORM 0: B rows per item step (8 / 4), whole rows per wave
+    constexpr int RPS = FORM == 0 ? NT / IPR_B : 0;           // FORM 0: B rows per item step, whole (half) rows per wave
     // row pitch of the B stage: 16 mod 32 doubles, so that the four k rows of a fragment read fall on different banks
-    constexpr int SB = FORM == 0 ? 144 : 16 * T + ((T & 1) ? 32 : 16);
+    constexpr int SB = FORM == 0 ? TILE + 16 : 16 * T + ((T & 1) ? 32 : 16);
     constexpr int A_STAGE = NA * RA * SA, B_STAGE = KT * SB;
     static_assert(FORM == 1 || (NT % IPR_B == 0 && KT % RPS == 0), "FORM 0: item steps cover whole B rows");
-    using Item = FastItem<VEC>;
+#ifdef QS_STRIP_FUSE_STORES      // experiment: a tile's stores ride between the products of the NEXT tile's first block.  Measured: the
+    constexpr bool kFuseStores = true;      // compiler then keeps two copies of the accumulators (spills from T = 9): off
+#else
+    constexpr bool kFuseStores = false;
+#endif
+    using Item = FastItem<true>;
     using item_t = typename Item::type;
 
     extern __shared__ __attribute__((aligned(16))) double smem[];
@@ -86,12 +93,6 @@ void gemm_strip_kernel(const StripArgs g) {
     const unsigned P = gridDim.x;
     const int k_tail = g.k - (nk - 1) * KT;                   // valid k of a tile's last stage (1 ... 16)
 
-    if (g.stagger_slots > 1) {      // (wave-uniform; a bounded loop: every wave leaves it)
-        const int steps = (int)((blockIdx.x >> 3) % (unsigned)g.stagger_slots);
-        const int64_t until = (int64_t)__builtin_amdgcn_s_memtime() + (int64_t)steps * g.stagger_cycles;
-        for (int i = 0; i < 4096 && (int64_t)__builtin_amdgcn_s_memtime() < until; ++i) __builtin_amdgcn_s_sleep(64);
-    }
-
     // ---- fetch cursor
     uint64_t a_ptr[NA];
     uint64_t b_ptr[FORM == 0 ? NB : 1];
@@ -103,16 +104,16 @@ void gemm_strip_kernel(const StripArgs g) {
     // start of tile w of the big extent
     auto tile_start = [&](unsigned v) -> int64_t {
         const unsigned w = xcd_chunked_index_fast(v, g.total);
-        return (int64_t)__builtin_amdgcn_readfirstlane((int)w) * 128;
+        return (int64_t)__builtin_amdgcn_readfirstlane((int)w) * TILE;
     };
     auto aim = [&](unsigned v) {
         const int64_t t0 = tile_start(v);
         if constexpr (FORM == 0) {
-            // virtual column j -> element (j / W) * sb + j % W of its B row; the tile's first segment goes into the scalar base
-            // (32-bit divisions: the host admits big + 256 < 2^32 only)
+            // virtual column j -> element (j / Wp) * sb + j % Wp of its B row; the tile's first segment goes into the scalar base
+            // (32-bit divisions: the host admits big + 512 < 2^32 only)
             const unsigned W = (unsigned)g.Wp;
             const unsigned seg0 = __builtin_amdgcn_readfirstlane((unsigned)t0 / W);
-            const unsigned j = (unsigned)t0 + (unsigned)(tid % IPR_B) * EPI;
+            const unsigned j = (unsigned)t0 + (unsigned)(tid % IPR_B) * 2;
             const unsigned sj = j / W;
             voff_b[0] = (unsigned)(((int64_t)(sj - seg0) * g.sb + (j - sj * W)) * 8);
             const char* Bb = reinterpret_cast<const char*>(g.B + (int64_t)seg0 * g.sb);
@@ -133,33 +134,32 @@ void gemm_strip_kernel(const StripArgs g) {
     // the pad columns of LDS row 0 and on an offset past the end of the (small) matrix
     unsigned st_b_off[FORM == 0 ? 1 : NB];
     if constexpr (FORM == 0) {
-        st_b_off[0] = (unsigned)((tid / IPR_B) * SB + (tid % IPR_B) * EPI);
+        st_b_off[0] = (unsigned)((tid / IPR_B) * SB + (tid % IPR_B) * 2);
     } else {
 #pragma unroll
         for (int i = 0; i < NB; ++i) {
             const int idx = tid + NT * i;
             const bool ok = idx < B_ITEMS;
             voff_b[i] = ok ? (unsigned)(idx / IPR_B) * (unsigned)g.ldb * 8u + (unsigned)(idx % IPR_B) * IB : 0x7FFFFFF0u;
-            st_b_off[i] = ok ? (unsigned)((idx / IPR_B) * SB + (idx % IPR_B) * EPI) : (unsigned)(16 * T + 2 * (tid & 7));
+            st_b_off[i] = ok ? (unsigned)((idx / IPR_B) * SB + (idx % IPR_B) * 2) : (unsigned)(16 * T + 2 * (tid & 7));
         }
     }
     aim(f_v);
     const size_t a_step = KT * 8;
     const size_t b_step = (size_t)KT * g.ldb * 8;
 
-    double* st_a = As + (tid / IPR_A) * SA + (tid % IPR_A) * EPI;
+    double* st_a = As + (tid / IPR_A) * SA + (tid % IPR_A) * 2;
     const double* rd_a = FORM == 0 ? As + (lane & 15) * SA + (lane >> 4)
-                                   : As + (wave * 16 + (lane & 15)) * SA + (lane >> 4);
-    const double* rd_b = FORM == 0 ? Bs + (lane >> 4) * SB + wave * 16 + (lane & 15)
+                                   : As + (wave * 16 * WN + (lane & 15)) * SA + (lane >> 4);
+    const double* rd_b = FORM == 0 ? Bs + (lane >> 4) * SB + wave * 16 * WN + (lane & 15)
                                    : Bs + (lane >> 4) * SB + (lane & 15);
 
     item_t ra[SETS][NA], rb[SETS][NB];
 
     // Loads are issued UNCONDITIONALLY (a cursor that has run out of tiles loads with a zero range: the descriptor returns
     // zeros without touching memory), and so is the write of the next stage to LDS: with a load count that does not depend on
-    // the path the compiler waits for exactly the loads a stage needs (vmcnt(n) with the newer register set still in flight)
-    // instead of draining to the newest one -- the second stage of lookahead is real.
-    auto fetch = [&](auto set_c) {
+    // the path the compiler can wait for exactly the loads a stage needs instead of draining to the newest one.
+    auto fetch = [&](auto set_c) __attribute__((always_inline)) {
         constexpr int set = decltype(set_c)::value;
 #ifdef QS_STRIP_ABLATE_LOADS      // development: no memory traffic on the load side (zero range: the descriptor answers with zeros)
         const unsigned live = 0u;
@@ -168,21 +168,13 @@ void gemm_strip_kernel(const StripArgs g) {
 #endif
 #pragma unroll
         for (int i = 0; i < NA; ++i) {
-#ifdef QS_STRIP_ABLATE_LOADS_A
-            ra[set][i] = Item::load(a_ptr[i], 0u, voff_a);
-#else
             ra[set][i] = Item::load(a_ptr[i], bytes_left(g.a_end, a_ptr[i]) & live, voff_a);
-#endif
             a_ptr[i] += a_step;
         }
         if constexpr (FORM == 0) {
 #pragma unroll
             for (int i = 0; i < NB; ++i) {
-#ifdef QS_STRIP_ABLATE_LOADS_B
-                rb[set][i] = Item::load(b_ptr[i], 0u, voff_b[0]);
-#else
                 rb[set][i] = Item::load(b_ptr[i], bytes_left(g.b_end, b_ptr[i]) & live, voff_b[0]);
-#endif
                 b_ptr[i] += b_step;
             }
         } else {
@@ -200,7 +192,7 @@ void gemm_strip_kernel(const StripArgs g) {
     };
 
     int s_k = 0;
-    auto stash = [&](auto buf_c, auto set_c) {
+    auto stash = [&](auto buf_c, auto set_c) __attribute__((always_inline)) {
         constexpr int buf = decltype(buf_c)::value;
         constexpr int set = decltype(set_c)::value;
         __builtin_amdgcn_sched_barrier(0);
@@ -210,12 +202,8 @@ void gemm_strip_kernel(const StripArgs g) {
             const item_t zero = item_t(0.0);
 #pragma unroll
             for (int i = 0; i < NA; ++i) {
-                if constexpr (VEC) {
-                    if ((tid % IPR_A) * 2 >= k_tail) ra[set][i][0] = 0.0;
-                    if ((tid % IPR_A) * 2 + 1 >= k_tail) ra[set][i][1] = 0.0;
-                } else {
-                    if ((tid % IPR_A) >= k_tail) ra[set][i] = zero;
-                }
+                if ((tid % IPR_A) * 2 >= k_tail) ra[set][i][0] = 0.0;
+                if ((tid % IPR_A) * 2 + 1 >= k_tail) ra[set][i][1] = 0.0;
             }
 #pragma unroll
             for (int i = 0; i < NB; ++i) {
@@ -224,93 +212,120 @@ void gemm_strip_kernel(const StripArgs g) {
             }
         }
 #pragma unroll
-        for (int i = 0; i < NA; ++i) {
-            double* d = st_a + buf * A_STAGE + i * RA * SA;
-            if constexpr (VEC) *reinterpret_cast<f64x2*>(d) = ra[set][i];
-            else d[0] = ra[set][i];
-        }
+        for (int i = 0; i < NA; ++i) *reinterpret_cast<f64x2*>(st_a + buf * A_STAGE + i * RA * SA) = ra[set][i];
 #pragma unroll
-        for (int i = 0; i < NB; ++i) {
-            double* d = Bs + buf * B_STAGE + (FORM == 0 ? st_b_off[0] + i * RPS * SB : st_b_off[i]);
-            if constexpr (VEC) *reinterpret_cast<f64x2*>(d) = rb[set][i];
-            else d[0] = rb[set][i];
-        }
+        for (int i = 0; i < NB; ++i)
+            *reinterpret_cast<f64x2*>(Bs + buf * B_STAGE + (FORM == 0 ? st_b_off[0] + i * RPS * SB : st_b_off[i])) = rb[set][i];
     };
 
-    f64x4 acc[T];
+    f64x4 acc[T][WN];      // [block of the small extent][the wave's block of the big extent]
 
     // fragments of k-step kk: the T shared ones (`sf`) and the wave's own (`of`)
-    auto read_frags = [&](auto buf_c, int kk, double (&sf)[T], double& of) {
+    auto read_frags = [&](auto buf_c, int kk, double (&sf)[T], double (&of)[WN]) __attribute__((always_inline)) {
         constexpr int buf = decltype(buf_c)::value;
         const double* as = rd_a + buf * A_STAGE;
         const double* bs = rd_b + buf * B_STAGE;
         if constexpr (FORM == 0) {
 #pragma unroll
             for (int i = 0; i < T; ++i) sf[i] = as[i * 16 * SA + kk * 4];
-            of = bs[kk * 4 * SB];
+#pragma unroll
+            for (int o = 0; o < WN; ++o) of[o] = bs[kk * 4 * SB + o * 16];
         } else {
-            of = as[kk * 4];
+#pragma unroll
+            for (int o = 0; o < WN; ++o) of[o] = as[o * 16 * SA + kk * 4];
 #pragma unroll
             for (int j = 0; j < T; ++j) sf[j] = bs[kk * 4 * SB + j * 16];
         }
     };
-    auto mfma_step = [&](const double (&sf)[T], const double of, auto fresh_c) {
+    auto mfma_block = [&](int s, const double (&sf)[T], const double (&of)[WN], auto fresh_c) __attribute__((always_inline)) {
         constexpr bool fresh = decltype(fresh_c)::value;
         const f64x4 zero = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-        for (int i = 0; i < T; ++i) {
-            if constexpr (FORM == 0) acc[i] = __builtin_amdgcn_mfma_f64_16x16x4f64(sf[i], of, fresh ? zero : acc[i], 0, 0, 0);
-            else acc[i] = __builtin_amdgcn_mfma_f64_16x16x4f64(of, sf[i], fresh ? zero : acc[i], 0, 0, 0);
+        for (int o = 0; o < WN; ++o) {
+            if constexpr (FORM == 0) acc[s][o] = __builtin_amdgcn_mfma_f64_16x16x4f64(sf[s], of[o], fresh ? zero : acc[s][o], 0, 0, 0);
+            else acc[s][o] = __builtin_amdgcn_mfma_f64_16x16x4f64(of[o], sf[s], fresh ? zero : acc[s][o], 0, 0, 0);
         }
     };
+    auto mfma_step = [&](const double (&sf)[T], const double (&of)[WN], auto fresh_c) __attribute__((always_inline)) {
+#pragma unroll
+        for (int s = 0; s < T; ++s) mfma_block(s, sf, of, fresh_c);
+    };
 
-    // register r of a lane holds row (lane >> 4) + 4 r, column lane & 15 of a 16 x 16 block: a store instruction writes four
-    // rows of 128 contiguous bytes
-    auto epilogue = [&](unsigned v) __attribute__((always_inline)) {
+    // ---- the result leaves through buffer stores: SGPR descriptor (base advanced per row on the scalar ALU) + one 32-bit lane
+    // offset per block; lanes that must not store carry an offset past the descriptor's range and are dropped by the hardware.
+    // No VALU instruction and no branch per store, so the stores of a tile ride between the products of its LAST block of
+    // matrix instructions (LAG blocks behind) instead of following them with the matrix pipe idle.
+    // register r of a lane holds row (lane >> 4) + 4 r, column lane & 15 of a 16 x 16 block.
+    constexpr unsigned kDropped = 0xFFFFFFFFu, kRange = 0x80000000u;
+    unsigned voff_c[WN];           // FORM 0: per tile; FORM 1: fixed (column block 0; later blocks through the immediate offset)
+    unsigned voff_c_last = 0;      // FORM 1: the same for the last column block (columns >= n dropped)
+    uint64_t c_base = 0;           // FORM 0: first segment of the tile;  FORM 1: first row of the wave in the tile
+    if constexpr (FORM == 1) {
+        voff_c[0] = (unsigned)(((int64_t)(lane >> 4) * g.ldc + (lane & 15)) * 8);
+        voff_c_last = ((T - 1) * 16 + (lane & 15) < g.small) ? voff_c[0] : kDropped;
+    }
+    auto aim_stores = [&](unsigned v) __attribute__((always_inline)) {
         const int64_t t0 = tile_start(v);
         if constexpr (FORM == 0) {
             const unsigned W = (unsigned)g.Wp;
-            const unsigned j = (unsigned)t0 + wave * 16 + (lane & 15);
-            const unsigned sj = j / W;
-#ifdef QS_STRIP_ABLATE_STORES_LOCAL      // development: every tile stores to the same few rows (the store instructions without their memory traffic)
-            double* __restrict__ C = g.C + (j & 127) + (int64_t)(lane >> 4) * g.ldc + (blockIdx.x & 255) * 128;
-#else
-            double* __restrict__ C = g.C + (int64_t)sj * g.sc + (j - sj * W) + (int64_t)(lane >> 4) * g.ldc;
-#endif
-#ifdef QS_STRIP_ABLATE_STORES     // development: no stores (the condition keeps the products alive)
-            const bool col_ok = acc[0][0] == 1.2345e300;
-#else
-            const bool col_ok = j < (unsigned)g.big && j - sj * W < (unsigned)g.W;
-#endif
+            const unsigned seg0 = __builtin_amdgcn_readfirstlane((unsigned)t0 / W);
+            c_base = uniform64(reinterpret_cast<uint64_t>(g.C + (int64_t)seg0 * g.sc));
 #pragma unroll
-            for (int i = 0; i < T; ++i) {
+            for (int o = 0; o < WN; ++o) {
+                const unsigned j = (unsigned)t0 + wave * 16 * WN + o * 16 + (lane & 15);
+                const unsigned sj = j / W;
+                const bool ok = j < (unsigned)g.big && j - sj * W < (unsigned)g.W;
+                voff_c[o] = ok ? (unsigned)(((int64_t)(sj - seg0) * g.sc + (j - sj * W) + (int64_t)(lane >> 4) * g.ldc) * 8) : kDropped;
+            }
+        } else {
+            c_base = uniform64(reinterpret_cast<uint64_t>(g.C + (t0 + wave * 16 * WN) * g.ldc));
+        }
+    };
+    auto store_block = [&](int s, uint64_t ldc8) __attribute__((always_inline)) {
+#ifndef QS_STRIP_ABLATE_STORES
+        if constexpr (FORM == 0) {
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int row = i * 16 + 4 * r + (lane >> 4);
-                    if (col_ok && (i < T - 1 || row < g.small))
-#ifdef QS_STRIP_ABLATE_STORES_LOCAL
-                        __builtin_nontemporal_store(acc[i][r], C + (int64_t)(4 * r) * g.ldc);
-#else
-                        __builtin_nontemporal_store(acc[i][r], C + (int64_t)(i * 16 + 4 * r) * g.ldc);
-#endif
+            for (int r = 0; r < 4; ++r) {
+                const uint64_t base = uniform64(c_base) + (uint64_t)(s * 16 + 4 * r) * ldc8;
+                const auto rsrc = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void*>(base), (short)0, (int)kRange, 0x00020000);
+#pragma unroll
+                for (int o = 0; o < WN; ++o) {
+                    unsigned off = voff_c[o];
+                    if (s == T - 1) off = (s * 16 + 4 * r + (lane >> 4) < g.small) ? off : kDropped;      // (last row block only)
+                    const double val = acc[s][o][r];      // (a bit cast of a vector ELEMENT reads element 0: through a scalar)
+                    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2_t, val), rsrc, (int)off, 0, 2);
                 }
             }
         } else {
-            const int64_t row0 = t0 + wave * 16 + (lane >> 4);
-            double* __restrict__ C = g.C + row0 * g.ldc + (lane & 15);
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-#ifdef QS_STRIP_ABLATE_STORES
-                const bool row_ok = acc[0][0] == 1.2345e300;
-#else
-                const bool row_ok = row0 + 4 * r < g.big;
-#endif
+            for (int o = 0; o < WN; ++o) {
 #pragma unroll
-                for (int jb = 0; jb < T; ++jb) {
-                    if (row_ok && (jb < T - 1 || jb * 16 + (lane & 15) < g.small))
-                        __builtin_nontemporal_store(acc[jb][r], C + (int64_t)(4 * r) * g.ldc + jb * 16);
+                for (int r = 0; r < 4; ++r) {
+                    const uint64_t base = uniform64(c_base) + (uint64_t)(o * 16 + 4 * r) * ldc8;
+                    // rows past the last one lie past the end of C: dropped by the range check
+                    const auto rsrc = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void*>(base), (short)0,
+                                                                        (int)bytes_left(g.c_end, base), 0x00020000);
+                    const unsigned off = (s == T - 1 ? voff_c_last : voff_c[0]);
+                    const double val = acc[s][o][r];
+                    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2_t, val), rsrc, (int)off, s * 128, 2);
                 }
             }
+        }
+#endif
+    };
+    // the FIRST block of a tile (fresh accumulators) carries the stores of the tile before it: the old values of block s leave,
+    // then the product of block s starts the new sum in the same registers -- whatever the position of a tile's last live
+    // block (K tails), the first one is always k-step 0 of its first stage
+    auto store_mfma_step = [&](const double (&sf)[T], const double (&of)[WN]) __attribute__((always_inline)) {
+        // (opaque per tile: the row offsets (16 s + 4 r) ldc are loop-invariant, and hoisted out of the kernel's main loop by
+        // the dozen they would not fit the scalar registers)
+        uint64_t ldc8 = (uint64_t)g.ldc * 8;
+        asm volatile("" : "+s"(ldc8));
+#pragma unroll
+        for (int s = 0; s < T; ++s) {
+            store_block(s, ldc8);
+            mfma_block(s, sf, of, std::true_type{});
+            __builtin_amdgcn_sched_barrier(0);
         }
     };
 
@@ -326,49 +341,68 @@ void gemm_strip_kernel(const StripArgs g) {
     fetch(B0{});                       // global stage 0
     stash(B0{}, B0{});
     __syncthreads();
-    double s0[T], s1[T], o0, o1;
+    double s0[T], s1[T], o0[WN], o1[WN];
     fetch(S1{});                       // stage 1
     if constexpr (SETS == 2) fetch(B0{});      // stage 2
     read_frags(B0{}, 0, s0, o0);
 
     unsigned c_v = blockIdx.x;
     int c_k = 0;
+    bool pending = false;      // a finished tile whose stores have not been issued yet
 
     // One global stage.  The LDS buffer the next stage goes into was last read before the PREVIOUS barrier, so it is free
     // from the start of this stage: the next stage is written (and the registers it leaves refilled from memory) right
-    // after the first block of MFMAs, two blocks ahead of the barrier -- with one workgroup per CU nothing else would cover
-    // the latency of those LDS writes (both waves of a SIMD reach the barrier together).
-    auto stage = [&](auto cur_c, int gs) {
+    // after the first block of MFMAs, two blocks ahead of the barrier.
+    auto stage = [&](auto cur_c, int gs) __attribute__((always_inline)) {
         constexpr int cur = decltype(cur_c)::value;
         using NXT = std::integral_constant<int, cur ^ 1>;
         using NSET = std::integral_constant<int, SETS == 2 ? (cur ^ 1) : 0>;
         const bool has_next = gs + 1 < stages;
-        const int ks_live = (c_k == nk - 1) ? (k_tail + 3) / 4 : KS;
+        const bool last = c_k == nk - 1;                        // last stage of its tile
+        const int ks_live = last ? (k_tail + 3) / 4 : KS;
+        // k-step kk of this stage on fragments (sf, of)
+        auto step = [&](int kk, const double (&sf)[T], const double (&of)[WN]) __attribute__((always_inline)) {
+            if (kk == 0 && c_k == 0) {
+                if constexpr (kFuseStores) { if (pending) store_mfma_step(sf, of); else mfma_step(sf, of, T_{}); }
+                else mfma_step(sf, of, T_{});
+            } else if (kk < ks_live) {
+                mfma_step(sf, of, F_{});
+            }
+        };
         read_frags(cur_c, 1, s1, o1);
         __builtin_amdgcn_sched_barrier(0);
-        if (c_k == 0) mfma_step(s0, o0, T_{}); else mfma_step(s0, o0, F_{});
+        step(0, s0, o0);
         __builtin_amdgcn_sched_barrier(0);
+        if constexpr (kFuseStores) {
+            if (last) { aim_stores(c_v); pending = true; }      // where this tile's result goes (it leaves with the next tile's first block)
+        }
         stash(NXT{}, NSET{});                    // stage gs + 1 (behind the last stage: zeros, never read)
         __builtin_amdgcn_sched_barrier(0);
         fetch(NSET{});                           // stage gs + 3 (two register sets) / gs + 2 (one)
         __builtin_amdgcn_sched_barrier(0);
         read_frags(cur_c, 2, s0, o0);
         __builtin_amdgcn_sched_barrier(0);
-        if (1 < ks_live) mfma_step(s1, o1, F_{});
+        step(1, s1, o1);
         __builtin_amdgcn_sched_barrier(0);
         read_frags(cur_c, 3, s1, o1);
         __builtin_amdgcn_sched_barrier(0);
-        if (2 < ks_live) mfma_step(s0, o0, F_{});
+        step(2, s0, o0);
         __builtin_amdgcn_sched_barrier(0);
 #ifndef QS_STRIP_ABLATE_BARRIER   // development: no stage barrier (results wrong; what the barrier costs)
         __syncthreads();
 #endif
         if (has_next) read_frags(NXT{}, 0, s0, o0);
         __builtin_amdgcn_sched_barrier(0);
-        if (3 < ks_live) mfma_step(s1, o1, F_{});
+        step(3, s1, o1);
         __builtin_amdgcn_sched_barrier(0);
         if (++c_k == nk) {
-            epilogue(c_v);
+            if constexpr (!kFuseStores) {      // the tile's result leaves behind its last block
+                aim_stores(c_v);
+                uint64_t ldc8 = (uint64_t)g.ldc * 8;
+                asm volatile("" : "+s"(ldc8));
+#pragma unroll
+                for (int s = 0; s < T; ++s) store_block(s, ldc8);
+            }
             c_k = 0;
             c_v += P;
         }
@@ -378,49 +412,64 @@ void gemm_strip_kernel(const StripArgs g) {
         stage(B0{}, gs);
         if (gs + 1 < stages) stage(B1{}, gs + 1);
     }
+    if (pending) {      // the last tile of this workgroup
+        uint64_t ldc8 = (uint64_t)g.ldc * 8;
+        asm volatile("" : "+s"(ldc8));
+#pragma unroll
+        for (int s = 0; s < T; ++s) store_block(s, ldc8);
+    }
 }
 
 namespace {
 
 // relative rate of a strip tile against the 128 x 128 tile of qs_gemm_fast.hip (same units as its shape weights)
-inline double strip_weight(int t, bool vec) {
+inline double strip_weight(int t, bool wide) {
     if (g_tune.gemm_strip_w > 0) return 0.01 * g_tune.gemm_strip_w;
     // (same-box sweep, profiles/r04_strip_sweep.txt: at equal tile extents -- l = 120, T = 8 -- the strip tile runs at 0.99 of
     // the 128 x 128 edge-form tile)
-    return (t >= 8 ? 1.0 : t >= 5 ? 0.95 : 0.80) * (vec ? 1.0 : 0.88);
+    return (t >= 8 ? 1.0 : t >= 5 ? 0.95 : 0.80) * (wide ? 1.06 : 1.0);
 }
 
-template <int FORM, int T, bool VEC>
-int launch_strip(const StripArgs& g, hipStream_t stream) {
-    constexpr int SETS = T <= 12 ? 2 : 1;
-    constexpr int EPI = VEC ? 2 : 1;
-    constexpr int RA = 512 / (16 / EPI);
-    constexpr int A_ROWS = FORM == 0 ? 16 * T : 128;
-    constexpr int NA = (A_ROWS + RA - 1) / RA;
-    constexpr int SB = FORM == 0 ? 144 : 16 * T + ((T & 1) ? 32 : 16);
-    const size_t lds = sizeof(double) * 2 * (size_t)(NA * RA * 18 + 16 * SB);
+template <int FORM, int T, int WN>
+int launch_strip(StripArgs g, hipStream_t stream) {
+    // two register sets of global data in flight where the registers allow it
+    constexpr int SETS = (T * WN <= 12) ? 2 : 1;
+    constexpr int TILE = 128 * WN;
+    constexpr int A_ROWS = FORM == 0 ? 16 * T : TILE;
+    constexpr int NA = (A_ROWS + 63) / 64;
+    constexpr int SB = FORM == 0 ? TILE + 16 : 16 * T + ((T & 1) ? 32 : 16);
+    const size_t lds = sizeof(double) * 2 * (size_t)(NA * 64 * 18 + 16 * SB);
+    const int64_t tiles = cdiv(g.big, TILE);
+    if (tiles * g.nk >= (int64_t(1) << 31)) return 1;
+    g.total = (unsigned)tiles;
     int64_t P = device_cu_count();
     P -= P % 8;
     if (P < 8) P = 8;
-    if (P > (int64_t)g.total) P = g.total;
-    auto kern = gemm_strip_kernel<FORM, T, VEC, SETS>;
+    if (P > tiles) P = tiles;
+    auto kern = gemm_strip_kernel<FORM, T, WN, SETS>;
     static PerDeviceLds lds_opt_in;
     if (int rc = opt_in_dynamic_lds((const void*)kern, lds, lds_opt_in, "hipFuncSetAttribute(gemm_strip)")) return rc;
     hipLaunchKernelGGL(kern, dim3((unsigned)P), dim3(512), lds, stream, g);
-    note_dispatch("qs::gemm_strip_kernel<%d, %d, %s, %d>", FORM, T, VEC ? "true" : "false", SETS);
+    note_dispatch("qs::gemm_strip_kernel<%d, %d, %d, %d>", FORM, T, WN, SETS);
     return launch_status("gemm_strip launch");
 }
 
-template <int FORM, bool VEC>
-int launch_strip_t(int t, const StripArgs& g, hipStream_t stream) {
+// wide: two blocks of 16 per wave along the big extent (tiles of 256): half the staging of the shared operand per product, where
+// the accumulators fit (T <= kWideMaxT) and the tile list is long enough to fill the chip
+constexpr int kWideMaxT = 10;
+
+template <int FORM>
+int launch_strip_t(int t, bool wide, const StripArgs& g, hipStream_t stream) {
     switch (t) {
 #ifdef QS_DEV_FEW_SHAPES      // development / sanitizer builds of the HOST side
-        case 9: return launch_strip<FORM, 9, VEC>(g, stream);
+        case 9: return wide ? launch_strip<FORM, 9, 2>(g, stream) : launch_strip<FORM, 9, 1>(g, stream);
 #else
-#define QS_STRIP(TT) case TT: return launch_strip<FORM, TT, VEC>(g, stream);
-        QS_STRIP(1) QS_STRIP(2) QS_STRIP(3) QS_STRIP(4) QS_STRIP(5) QS_STRIP(6) QS_STRIP(7) QS_STRIP(8)
-        QS_STRIP(9) QS_STRIP(10) QS_STRIP(11) QS_STRIP(12) QS_STRIP(13) QS_STRIP(14) QS_STRIP(15) QS_STRIP(16)
+#define QS_STRIP(TT) case TT: return launch_strip<FORM, TT, 1>(g, stream);
+#define QS_STRIP_W(TT) case TT: return wide ? launch_strip<FORM, TT, 2>(g, stream) : launch_strip<FORM, TT, 1>(g, stream);
+        QS_STRIP_W(1) QS_STRIP_W(2) QS_STRIP_W(3) QS_STRIP_W(4) QS_STRIP_W(5) QS_STRIP_W(6) QS_STRIP_W(7) QS_STRIP_W(8)
+        QS_STRIP_W(9) QS_STRIP_W(10) QS_STRIP(11) QS_STRIP(12) QS_STRIP(13) QS_STRIP(14) QS_STRIP(15) QS_STRIP(16)
 #undef QS_STRIP
+#undef QS_STRIP_W
 #endif
         default: return 1;
     }
@@ -454,46 +503,35 @@ int gemm_strip_try(int dtype, const double* A, const double* B, double* C, int64
         // past the last one of the last tile compute offsets of their own -- whatever they address is either inside the
         // operand or cut off by the range check of the buffer descriptor, and they are never stored.)
         if (sb < 0 || sc < 0 || lda < k || ldb < n || ldc < n) return 1;
-        if ((128 / n + 2) * sb * 8 + n * 8 >= (int64_t(1) << 32) - 65536 || 64 * lda * 8 >= (int64_t(1) << 31)) return 1;
+        if ((256 / n + 2) * sb * 8 + n * 8 >= (int64_t(1) << 32) - 65536 || 64 * lda * 8 >= (int64_t(1) << 31)) return 1;
+        if (((256 / n + 2) * sc + n + 4 * ldc) * 8 >= (int64_t(1) << 31)) return 1;      // store offsets stay below the descriptor's range
         g.W = n; g.Wp = n + (n & 1);
-        if (g.Wp * batch + 256 >= (int64_t(1) << 32)) return 1;      // the kernel's column arithmetic is 32-bit
+        if (g.Wp * batch + 512 >= (int64_t(1) << 32)) return 1;      // the kernel's column arithmetic is 32-bit
         g.big = g.Wp * batch; g.small = (int)m;
         t = (int)cdiv(m, 16);
     } else {
         if (lda < k || ldb < n || ldc < n) return 1;
-        if (64 * lda * 8 >= (int64_t(1) << 31) || 16 * ldb * 8 + 4096 >= (int64_t(1) << 30)) return 1;
+        if (64 * lda * 8 >= (int64_t(1) << 31) || 16 * ldb * 8 + 4096 >= (int64_t(1) << 30) || 4 * ldc * 8 + 4096 >= (int64_t(1) << 31)) return 1;
         g.big = m; g.W = g.Wp = 0; g.small = (int)n;
         t = (int)cdiv(n, 16);
     }
-    const int64_t tiles = cdiv(g.big, 128);
-    if (tiles * cdiv(k, 16) >= (int64_t(1) << 31)) return 1;
-    {   // stagger of the workgroups' starts (experiment: QS_STRIP_STAGGER = slots, 0 / unset = off)
-        static const int slots = [] { const char* e = getenv("QS_STRIP_STAGGER"); return e ? atoi(e) : 0; }();
-        g.stagger_slots = slots;
-        // one tile = nk stages x 4 k-steps x t products x 64 cycles x two waves per SIMD, at ~0.75 of the matrix rate
-        g.stagger_cycles = slots > 1 ? (int)(cdiv(k, 16) * 4 * t * 64 * 2 * 4 / 3 / slots) : 0;
-    }
-    g.total = (unsigned)tiles;
     g.a_end = reinterpret_cast<uint64_t>(A) + (uint64_t)(((m - 1) * lda + k) * 8);
     g.b_end = reinterpret_cast<uint64_t>(B) + (uint64_t)(((batch - 1) * sb + (k - 1) * ldb + n) * 8);
-#ifdef QS_STRIP_ITEMS8
-    const bool vec = aligned(A, 16) && aligned(B, 16) && !(lda & 1) && !(ldb & 1) && !(sb & 1) && !(n & 1) && !(k & 1);
-#else
-    const bool vec = true;
-#endif
+    g.c_end = reinterpret_cast<uint64_t>(C) + (uint64_t)(((batch - 1) * sc + (m - 1) * ldc + n) * 8);
+    // wide tiles (256 of the big extent) where the accumulators fit and the list still fills the chip a few times over
+    const double slots = device_cu_count();
+    static const int wide_env = [] { const char* e = getenv("QS_STRIP_WIDE"); return e ? atoi(e) : -1; }();      // (tuning runs)
+    bool wide = t <= kWideMaxT && cdiv(g.big, 256) >= 4 * (int64_t)slots;
+    if (wide_env >= 0) wide = wide_env != 0 && t <= kWideMaxT;
+    const int64_t tiles = cdiv(g.big, wide ? 256 : 128);
     if (g_tune.gemm_strip == 1) {
         // estimated time: rounds of the tile list over the CUs (one eight-wave workgroup each = both slots of the other
         // kernels' two four-wave workgroups) x tile area / relative rate
-        const double slots = device_cu_count();
         const double rounds = tiles > 8 * slots ? tiles / slots : ceil(tiles / slots);
-        const double cost = rounds * (16.0 * t) * 128.0 / 2.0 / strip_weight(t, vec);
+        const double cost = rounds * (16.0 * t) * (wide ? 256.0 : 128.0) / 2.0 / strip_weight(t, wide);
         if (!(cost < other_cost)) return 1;
     }
-#ifdef QS_STRIP_ITEMS8
-    if (!vec) { g.Wp = g.W; g.big = form == 0 ? n * batch : m; g.total = (unsigned)cdiv(g.big, 128); }
-    if (!vec) return form == 0 ? launch_strip_t<0, false>(t, g, stream) : launch_strip_t<1, false>(t, g, stream);
-#endif
-    return form == 0 ? launch_strip_t<0, true>(t, g, stream) : launch_strip_t<1, true>(t, g, stream);
+    return form == 0 ? launch_strip_t<0>(t, wide, g, stream) : launch_strip_t<1>(t, wide, g, stream);
 }
 
 }  // namespace qs

@@ -102,8 +102,16 @@ def test_two_rank_self_launch(layout):
     res = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=ROOT, env=env)
     assert res.returncode == 0, res.stderr[-3000:]
     lines = [ln for ln in res.stdout.splitlines() if ln.strip()]
-    assert len(lines) == 1, res.stdout[-2000:]                 # exactly one line on the parent's stdout
-    d = json.loads(lines[0])
+    if layout == "auto":
+        # a COMPLETE provisional line after every leg (whatever happens to the legs still to come, the last line on stdout
+        # carries everything measured so far), the final line last and without the flag
+        every = [json.loads(ln) for ln in lines]
+        assert len(every) == 5 and all(e.get("provisional") is True for e in every[:-1]) and "provisional" not in every[-1]
+        assert [len(e["legs"]) for e in every] == [1, 2, 3, 4, 5] and every[0]["legs_pending"] == ["rows", "rows_rccl", "rows_rccl_coalesced", "rccl"]
+        assert all(e["value"] > 0 and e["parity"]["ok"] for e in every)
+    else:
+        assert len(lines) == 1, res.stdout[-2000:]                 # exactly one line on the parent's stdout
+    d = json.loads(lines[-1])
     assert d["n_gpus"] == 2 and d["n_ranks_seen"] == 2 and d["steps"] == 3 and d["value"] > 0
     assert d["parity"]["ok"] is True and d["parity"]["randomised_identity_rel_diff"] <= 1e-10
     if layout == "replicated":
@@ -113,13 +121,13 @@ def test_two_rank_self_launch(layout):
         # the driver's one command: every layout measured as its own group of rank processes, ONE line; `value` is the
         # best leg whose time includes a collective, and it is named
         legs = d["legs"]
-        assert list(legs) == ["replicated", "rows", "rows_rccl", "rccl"]
+        assert list(legs) == ["replicated", "rows", "rows_rccl", "rows_rccl_coalesced", "rccl"]
         assert legs["replicated"]["status"] == "ok" and legs["rows"]["status"] == "ok"
         assert legs["replicated"]["collective"] == "none" and legs["replicated"]["with_all_gather"]["value"] > 0
         assert "all-to-all per chunk" in legs["rows"]["collective"] and legs["rows"]["parity"]["ok"] is True
         # RCCL driven directly needs one GPU per rank: in the one-device rehearsal those legs are recorded as failed
         # and cost nothing else
-        assert legs["rows_rccl"]["status"].startswith("failed") and legs["rccl"]["status"].startswith("failed")
+        assert all(legs[x]["status"].startswith("failed") for x in ("rows_rccl", "rows_rccl_coalesced", "rccl"))
         assert d["config"]["chosen_leg"] in ("rows", "replicated + all-gather")
         assert d["collective"]["in_value"] != "none"
         best = max(legs["rows"]["value"], legs["replicated"]["with_all_gather"]["value"])
@@ -139,12 +147,41 @@ def test_default_layout_under_the_external_launcher_runs_every_leg():
     res = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
     assert res.returncode == 0, res.stderr[-3000:]
     lines = [ln for ln in res.stdout.splitlines() if ln.strip().startswith("{")]
-    assert len(lines) == 1, res.stdout[-2000:]
-    d = json.loads(lines[0])
+    assert len(lines) == 3, res.stdout[-2000:]                 # a provisional line after each of the first two legs, then the final one
+    assert all(json.loads(ln).get("provisional") is True for ln in lines[:-1])
+    d = json.loads(lines[-1])
+    assert "provisional" not in d
     assert d["n_gpus"] == 2 and d["n_ranks_seen"] == 2 and d["parity"]["ok"] is True
     assert d["legs"]["replicated"]["status"] == "ok" and d["legs"]["rows"]["status"] == "ok"
     assert d["legs"]["rows_rccl"]["status"].startswith("failed")
     assert d["config"]["chosen_leg"] in ("rows", "replicated + all-gather") and d["value"] > 0
+
+
+def test_a_hanging_leg_costs_only_itself_and_the_run_stays_inside_its_budget():
+    # VERDICT r03 "next" 1c: the legs that drive RCCL directly have never run on more than one rank before the driver's node.
+    # Rehearsal of the worst case: a leg that HANGS (QS_BENCH_HANG_LEG, a test hook: the leg's rank processes sleep instead of
+    # measuring).  Its ranks are killed at --leg-timeout, the legs measured before it are already on stdout as a complete
+    # provisional line, the legs after it still run, the final line carries all of them, and nothing runs past --total-budget.
+    import time
+
+    env = dict(os.environ, **REHEARSAL, QS_BENCH_HANG_LEG="rows_rccl")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT"):
+        env.pop(k, None)
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--orbitals", "48",
+           "--no-cpu-baseline", "--no-probes", "--legs", "replicated,rows_rccl,rows", "--leg-timeout", "20", "--total-budget", "150"]
+    t0 = time.monotonic()
+    res = subprocess.run(cmd, capture_output=True, text=True, timeout=400, cwd=ROOT, env=env)
+    wall = time.monotonic() - t0
+    assert res.returncode == 0, res.stderr[-3000:]
+    assert wall < 150, wall
+    lines = [json.loads(ln) for ln in res.stdout.splitlines() if ln.strip().startswith("{")]
+    assert len(lines) == 3 and lines[0]["provisional"] is True and list(lines[0]["legs"]) == ["replicated"]
+    assert lines[0]["value"] > 0 and lines[0]["parity"]["ok"] is True          # what stands if everything after it is lost
+    d = lines[-1]
+    assert "provisional" not in d and list(d["legs"]) == ["replicated", "rows_rccl", "rows"]
+    assert "timed out" in d["legs"]["rows_rccl"]["status"] and 18 <= d["legs"]["rows_rccl"]["wall_s"] <= 40
+    assert d["legs"]["replicated"]["status"] == "ok" and d["legs"]["rows"]["status"] == "ok"
+    assert d["config"]["chosen_leg"] in ("rows", "replicated + all-gather") and d["parity"]["ok"] is True
 
 
 def test_rows_layouts_with_a_one_rank_group():

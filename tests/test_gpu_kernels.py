@@ -590,6 +590,7 @@ def test_fitted_tile_shapes_vs_oracle(K, m, n, k, batch):
     try:
         K.tuning_set("gemm_fast", 0)
         K.tuning_set("gemm_fit", 0)
+        K.tuning_set("gemm_strip", 0)          # (round 4: the strip kernels would take these products first)
         general = host(K.matmul(dev(A), dev(B)))
         assert "gemm_kernel<2, 2" in K.last_dispatch()
         K.tuning_set("gemm_fit", 2)
