@@ -540,14 +540,21 @@ int gemm_c128(const double* A, const double* B, double* C, int64_t m, int64_t n,
         if (rc != 1) return rc;
         rc = gemm_stream_try(QS_C128, A, B, C, m, n, k, lda, ldb, ldc, batch, sa, sb, sc, accumulate, stream);
         if (rc != 1) return rc;
-        rc = gemm_fast_try(QS_C128, A, B, C, m, n, k, lda, ldb, ldc, batch, sa, sb, sc,
-                           accumulate, g.group_along_m, 0.0, stream);
-        if (rc != 1) return rc;
         static const TileShape cand[] = {
             {1, 64, 128, 1.00}, {2, 128, 64, 1.00}, {6, 64, 64, 1.00}, {9, 96, 96, 0.97},
             {7, 96, 64, 0.95},  {8, 64, 96, 0.95},  {4, 32, 32, 0.94},
         };
-        cfg = pick_shape(cand, sizeof(cand) / sizeof(cand[0]), m, n, batch);
+        double cost = 0.0;
+        cfg = pick_shape(cand, sizeof(cand) / sizeof(cand[0]), m, n, batch, &cost);
+        if (g_tune.gemm_strip == 2 || g_tune.gemm_fast == 1) {
+            // strip kernels (qs_gemm_strip.hip), complex form: a basis of up to 128 orbitals covered by one tile to the next multiple of 16
+            const double fast = gemm_fast_estimate(QS_C128, m, n, k, batch, true);
+            rc = gemm_strip_try(QS_C128, A, B, C, m, n, k, lda, ldb, ldc, batch, sa, sb, sc, accumulate, fast < cost ? fast : cost, stream);
+            if (rc != 1) return rc;
+        }
+        rc = gemm_fast_try(QS_C128, A, B, C, m, n, k, lda, ldb, ldc, batch, sa, sb, sc,
+                           accumulate, g.group_along_m, 0.0, stream);
+        if (rc != 1) return rc;
     }
     switch (cfg) {
         case 1: return launch_one<2, 2, 2, 4, 8, MODE_C128>(g, batch, stream);   //  64 x 128

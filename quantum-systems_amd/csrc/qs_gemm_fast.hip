@@ -525,8 +525,9 @@ double gemm_fast_estimate(int dtype, int64_t m, int64_t n, int64_t k, int64_t ba
         if (m % 128 == 0 && n % 128 == 0) return whole(128, 128, 1.12);
         if (m % 64 == 0 && n % 128 == 0) return whole(64, 128, 1.04);
     }
-    if (cx) {
-        if (k % 8 == 0 && m % 64 == 0 && n % 64 == 0) return whole(64, 64, 0.95);
+    if (cx) {      // (units of the complex tile shapes: the 64 x 128 tile = 1)
+        if (k % 8 == 0 && ((m % 128 == 0 && n % 64 == 0) || (m % 64 == 0 && n % 128 == 0))) return whole(m % 128 == 0 ? 128 : 64, m % 128 == 0 ? 64 : 128, 1.10);
+        if (k % 8 == 0 && m % 64 == 0 && n % 64 == 0) return whole(64, 64, 1.04);
         return 1e300;
     }
     double cost = 1e300;

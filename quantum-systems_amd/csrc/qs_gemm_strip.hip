@@ -36,49 +36,52 @@
 namespace qs {
 
 typedef unsigned u32x2_t __attribute__((ext_vector_type(2)));
+typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
 
 struct StripArgs {
     const double* A;
     const double* B;
     double* C;
     int64_t lda, ldb, ldc;   // elements
-    int64_t sb, sc;          // FORM 0: distance between the column segments (batch entries) of B and of C
+    int64_t sb, sc;          // FORM 0: distance between the column segments (batch entries) of B and of C (elements)
     uint64_t a_end, b_end, c_end;   // one past the last byte of each operand
     int64_t big;             // FORM 0: virtual columns (segments x Wp);  FORM 1: rows m
     int64_t W;               // FORM 0: columns per segment
-    int64_t Wp;              // FORM 0: W rounded up to even: the width of a segment in VIRTUAL columns -- an odd segment gets one
-                             // dummy column at its end, so that a 16-byte item (two adjacent columns) never straddles two segments
+    int64_t Wp;              // FORM 0, fp64: W rounded up to even: the width of a segment in VIRTUAL columns -- an odd segment gets
+                             // one dummy column at its end, so that a 16-byte item (two adjacent columns) never straddles two segments
     int small;               // FORM 0: rows m (of A and of the result);  FORM 1: columns n
-    int k, nk;               // K, ceil(K / 16)
+    int k, nk;               // K, ceil(K / KT)
     unsigned total;          // tiles
 };
 
-// T = blocks of 16 along the small extent (shared fragments), WN = blocks of 16 per wave along the big extent (tile = 128 WN
-// of it), SETS = register sets of global data in flight (2: two stages of lookahead).
-template <int FORM, int T, int WN, int SETS>
+// CX = complex128 (re / im planes in LDS, four real matrix instructions per fragment pair in the order of the other tiled kernels:
+// re += ar br, im += ar bi, re += (-ai) bi, im += ai br with a / b the LEFT / RIGHT operand of the product), T = blocks of 16
+// along the small extent (shared fragments), WN = blocks of 16 per wave along the big extent (tile = 128 WN of it), SETS =
+// register sets of global data in flight (2: two stages of lookahead).
+template <bool CX, int FORM, int T, int WN, int SETS>
 __global__ __launch_bounds__(512, 1)
 void gemm_strip_kernel(const StripArgs g) {
-    constexpr int KT = 16, KS = 4, NT = 512, SA = KT + 2;
-    constexpr unsigned IB = 16;                               // bytes per global item (two elements)
-    constexpr int IPR_A = KT / 2;                             // items per A row of a stage
+    constexpr int NP = CX ? 2 : 1;                            // LDS planes
+    constexpr int KT = CX ? 8 : 16, KS = KT / 4, NT = 512, SA = KT + 2;
+    constexpr int EPI = CX ? 1 : 2;                           // elements per 16-byte global item
+    constexpr unsigned ESZ = CX ? 16 : 8;                     // bytes per element
+    constexpr unsigned IB = 16;                               // bytes per global item
+    constexpr int IPR_A = KT / EPI;                           // items per A row of a stage (8)
     constexpr int RA = NT / IPR_A;                            // A rows covered by one item step (64)
     constexpr int TILE = 128 * WN;                            // extent of a tile along the big extent
     constexpr int A_ROWS = FORM == 0 ? 16 * T : TILE;
     constexpr int NA = (A_ROWS + RA - 1) / RA;                // item steps of the A stage
     constexpr int B_COLS = FORM == 0 ? TILE : 16 * T;
-    constexpr int IPR_B = B_COLS / 2;                         // items per B row
+    constexpr int IPR_B = B_COLS / EPI;                       // items per B row
     constexpr int B_ITEMS = KT * IPR_B;
     constexpr int NB = (B_ITEMS + NT - 1) / NT;               // item steps of the B stage
     constexpr int RPS = FORM == 0 ? NT / IPR_B : 0;           // FORM 0: B rows per item step, whole (half) rows per wave
     // row pitch of the B stage: 16 mod 32 doubles, so that the four k rows of a fragment read fall on different banks
     constexpr int SB = FORM == 0 ? TILE + 16 : 16 * T + ((T & 1) ? 32 : 16);
-    constexpr int A_STAGE = NA * RA * SA, B_STAGE = KT * SB;
+    constexpr int A_PLANE = NA * RA * SA, B_PLANE = KT * SB;
+    constexpr int A_STAGE = NP * A_PLANE, B_STAGE = NP * B_PLANE;
     static_assert(FORM == 1 || (NT % IPR_B == 0 && KT % RPS == 0), "FORM 0: item steps cover whole B rows");
-#ifdef QS_STRIP_FUSE_STORES      // experiment: a tile's stores ride between the products of the NEXT tile's first block.  Measured: the
-    constexpr bool kFuseStores = true;      // compiler then keeps two copies of the accumulators (spills from T = 9): off
-#else
-    constexpr bool kFuseStores = false;
-#endif
+    static_assert(KS == 2 || KS == 4, "two or four k-steps per stage");
     using Item = FastItem<true>;
     using item_t = typename Item::type;
 
@@ -91,7 +94,7 @@ void gemm_strip_kernel(const StripArgs g) {
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int nk = g.nk;
     const unsigned P = gridDim.x;
-    const int k_tail = g.k - (nk - 1) * KT;                   // valid k of a tile's last stage (1 ... 16)
+    const int k_tail = g.k - (nk - 1) * KT;                   // valid k of a tile's last stage (1 ... KT)
 
     // ---- fetch cursor
     uint64_t a_ptr[NA];
@@ -100,55 +103,55 @@ void gemm_strip_kernel(const StripArgs g) {
     unsigned f_v = blockIdx.x;
     int f_k = 0;
     bool f_valid = true;
-    const unsigned voff_a = (unsigned)(tid / IPR_A) * (unsigned)g.lda * 8u + (unsigned)(tid % IPR_A) * IB;
+    const unsigned voff_a = (unsigned)(tid / IPR_A) * (unsigned)g.lda * ESZ + (unsigned)(tid % IPR_A) * IB;
     // start of tile w of the big extent
     auto tile_start = [&](unsigned v) -> int64_t {
         const unsigned w = xcd_chunked_index_fast(v, g.total);
         return (int64_t)__builtin_amdgcn_readfirstlane((int)w) * TILE;
     };
-    auto aim = [&](unsigned v) {
+    auto aim = [&](unsigned v) __attribute__((always_inline)) {
         const int64_t t0 = tile_start(v);
         if constexpr (FORM == 0) {
             // virtual column j -> element (j / Wp) * sb + j % Wp of its B row; the tile's first segment goes into the scalar base
             // (32-bit divisions: the host admits big + 512 < 2^32 only)
             const unsigned W = (unsigned)g.Wp;
             const unsigned seg0 = __builtin_amdgcn_readfirstlane((unsigned)t0 / W);
-            const unsigned j = (unsigned)t0 + (unsigned)(tid % IPR_B) * 2;
+            const unsigned j = (unsigned)t0 + (unsigned)(tid % IPR_B) * EPI;
             const unsigned sj = j / W;
-            voff_b[0] = (unsigned)(((int64_t)(sj - seg0) * g.sb + (j - sj * W)) * 8);
-            const char* Bb = reinterpret_cast<const char*>(g.B + (int64_t)seg0 * g.sb);
+            voff_b[0] = (unsigned)(((int64_t)(sj - seg0) * g.sb + (j - sj * W)) * ESZ);
+            const char* Bb = reinterpret_cast<const char*>(g.B) + (int64_t)seg0 * g.sb * ESZ;
 #pragma unroll
             for (int i = 0; i < NB; ++i)
-                b_ptr[i] = uniform64(reinterpret_cast<uint64_t>(Bb + (size_t)(wave * 64 / IPR_B + i * RPS) * g.ldb * 8));
+                b_ptr[i] = uniform64(reinterpret_cast<uint64_t>(Bb + (size_t)(wave * 64 / IPR_B + i * RPS) * g.ldb * ESZ));
 #pragma unroll
             for (int i = 0; i < NA; ++i)
-                a_ptr[i] = uniform64(reinterpret_cast<uint64_t>(reinterpret_cast<const char*>(g.A) + (size_t)i * RA * g.lda * 8));
+                a_ptr[i] = uniform64(reinterpret_cast<uint64_t>(reinterpret_cast<const char*>(g.A) + (size_t)i * RA * g.lda * ESZ));
         } else {
 #pragma unroll
             for (int i = 0; i < NA; ++i)
-                a_ptr[i] = uniform64(reinterpret_cast<uint64_t>(reinterpret_cast<const char*>(g.A) + (size_t)(t0 + i * RA) * g.lda * 8));
+                a_ptr[i] = uniform64(reinterpret_cast<uint64_t>(reinterpret_cast<const char*>(g.A) + (size_t)(t0 + i * RA) * g.lda * ESZ));
             b_ptr[0] = uniform64(reinterpret_cast<uint64_t>(g.B));
         }
     };
-    // FORM 1: the B stage (a 16 x 16 T piece of the coefficient matrix) as a flat item list; threads beyond it are parked on
+    // FORM 1: the B stage (a KT x 16 T piece of the coefficient matrix) as a flat item list; threads beyond it are parked on
     // the pad columns of LDS row 0 and on an offset past the end of the (small) matrix
     unsigned st_b_off[FORM == 0 ? 1 : NB];
     if constexpr (FORM == 0) {
-        st_b_off[0] = (unsigned)((tid / IPR_B) * SB + (tid % IPR_B) * 2);
+        st_b_off[0] = (unsigned)((tid / IPR_B) * SB + (tid % IPR_B) * EPI);
     } else {
 #pragma unroll
         for (int i = 0; i < NB; ++i) {
             const int idx = tid + NT * i;
             const bool ok = idx < B_ITEMS;
-            voff_b[i] = ok ? (unsigned)(idx / IPR_B) * (unsigned)g.ldb * 8u + (unsigned)(idx % IPR_B) * IB : 0x7FFFFFF0u;
-            st_b_off[i] = ok ? (unsigned)((idx / IPR_B) * SB + (idx % IPR_B) * 2) : (unsigned)(16 * T + 2 * (tid & 7));
+            voff_b[i] = ok ? (unsigned)(idx / IPR_B) * (unsigned)g.ldb * ESZ + (unsigned)(idx % IPR_B) * IB : 0x7FFFFFF0u;
+            st_b_off[i] = ok ? (unsigned)((idx / IPR_B) * SB + (idx % IPR_B) * EPI) : (unsigned)(16 * T + 2 * (tid & 7));
         }
     }
     aim(f_v);
-    const size_t a_step = KT * 8;
-    const size_t b_step = (size_t)KT * g.ldb * 8;
+    const size_t a_step = KT * ESZ;
+    const size_t b_step = (size_t)KT * g.ldb * ESZ;
 
-    double* st_a = As + (tid / IPR_A) * SA + (tid % IPR_A) * 2;
+    double* st_a = As + (tid / IPR_A) * SA + (tid % IPR_A) * EPI;
     const double* rd_a = FORM == 0 ? As + (lane & 15) * SA + (lane >> 4)
                                    : As + (wave * 16 * WN + (lane & 15)) * SA + (lane >> 4);
     const double* rd_b = FORM == 0 ? Bs + (lane >> 4) * SB + wave * 16 * WN + (lane & 15)
@@ -202,8 +205,12 @@ void gemm_strip_kernel(const StripArgs g) {
             const item_t zero = item_t(0.0);
 #pragma unroll
             for (int i = 0; i < NA; ++i) {
-                if ((tid % IPR_A) * 2 >= k_tail) ra[set][i][0] = 0.0;
-                if ((tid % IPR_A) * 2 + 1 >= k_tail) ra[set][i][1] = 0.0;
+                if constexpr (CX) {
+                    if ((tid % IPR_A) >= k_tail) ra[set][i] = zero;
+                } else {
+                    if ((tid % IPR_A) * 2 >= k_tail) ra[set][i][0] = 0.0;
+                    if ((tid % IPR_A) * 2 + 1 >= k_tail) ra[set][i][1] = 0.0;
+                }
             }
 #pragma unroll
             for (int i = 0; i < NB; ++i) {
@@ -212,56 +219,74 @@ void gemm_strip_kernel(const StripArgs g) {
             }
         }
 #pragma unroll
-        for (int i = 0; i < NA; ++i) *reinterpret_cast<f64x2*>(st_a + buf * A_STAGE + i * RA * SA) = ra[set][i];
+        for (int i = 0; i < NA; ++i) {
+            double* d = st_a + buf * A_STAGE + i * RA * SA;
+            if constexpr (CX) { d[0] = ra[set][i][0]; d[A_PLANE] = ra[set][i][1]; }
+            else *reinterpret_cast<f64x2*>(d) = ra[set][i];
+        }
 #pragma unroll
-        for (int i = 0; i < NB; ++i)
-            *reinterpret_cast<f64x2*>(Bs + buf * B_STAGE + (FORM == 0 ? st_b_off[0] + i * RPS * SB : st_b_off[i])) = rb[set][i];
+        for (int i = 0; i < NB; ++i) {
+            double* d = Bs + buf * B_STAGE + (FORM == 0 ? st_b_off[0] + i * RPS * SB : st_b_off[i]);
+            if constexpr (CX) { d[0] = rb[set][i][0]; d[B_PLANE] = rb[set][i][1]; }
+            else *reinterpret_cast<f64x2*>(d) = rb[set][i];
+        }
     };
 
-    f64x4 acc[T][WN];      // [block of the small extent][the wave's block of the big extent]
+    f64x4 acc[NP][T][WN];      // [re | im][block of the small extent][the wave's block of the big extent]
 
     // fragments of k-step kk: the T shared ones (`sf`) and the wave's own (`of`)
-    auto read_frags = [&](auto buf_c, int kk, double (&sf)[T], double (&of)[WN]) __attribute__((always_inline)) {
+    auto read_frags = [&](auto buf_c, int kk, double (&sf)[NP][T], double (&of)[NP][WN]) __attribute__((always_inline)) {
         constexpr int buf = decltype(buf_c)::value;
         const double* as = rd_a + buf * A_STAGE;
         const double* bs = rd_b + buf * B_STAGE;
-        if constexpr (FORM == 0) {
 #pragma unroll
-            for (int i = 0; i < T; ++i) sf[i] = as[i * 16 * SA + kk * 4];
+        for (int p = 0; p < NP; ++p) {
+            if constexpr (FORM == 0) {
 #pragma unroll
-            for (int o = 0; o < WN; ++o) of[o] = bs[kk * 4 * SB + o * 16];
-        } else {
+                for (int i = 0; i < T; ++i) sf[p][i] = as[p * A_PLANE + i * 16 * SA + kk * 4];
 #pragma unroll
-            for (int o = 0; o < WN; ++o) of[o] = as[o * 16 * SA + kk * 4];
+                for (int o = 0; o < WN; ++o) of[p][o] = bs[p * B_PLANE + kk * 4 * SB + o * 16];
+            } else {
 #pragma unroll
-            for (int j = 0; j < T; ++j) sf[j] = bs[kk * 4 * SB + j * 16];
+                for (int o = 0; o < WN; ++o) of[p][o] = as[p * A_PLANE + o * 16 * SA + kk * 4];
+#pragma unroll
+                for (int j = 0; j < T; ++j) sf[p][j] = bs[p * B_PLANE + kk * 4 * SB + j * 16];
+            }
         }
     };
-    auto mfma_block = [&](int s, const double (&sf)[T], const double (&of)[WN], auto fresh_c) __attribute__((always_inline)) {
+    auto mfma_step = [&](const double (&sf)[NP][T], const double (&of)[NP][WN], auto fresh_c) __attribute__((always_inline)) {
         constexpr bool fresh = decltype(fresh_c)::value;
         const f64x4 zero = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-        for (int o = 0; o < WN; ++o) {
-            if constexpr (FORM == 0) acc[s][o] = __builtin_amdgcn_mfma_f64_16x16x4f64(sf[s], of[o], fresh ? zero : acc[s][o], 0, 0, 0);
-            else acc[s][o] = __builtin_amdgcn_mfma_f64_16x16x4f64(of[o], sf[s], fresh ? zero : acc[s][o], 0, 0, 0);
-        }
-    };
-    auto mfma_step = [&](const double (&sf)[T], const double (&of)[WN], auto fresh_c) __attribute__((always_inline)) {
+        for (int s = 0; s < T; ++s) {
 #pragma unroll
-        for (int s = 0; s < T; ++s) mfma_block(s, sf, of, fresh_c);
+            for (int o = 0; o < WN; ++o) {
+                // a = fragment of the LEFT operand, b = of the RIGHT one
+                if constexpr (!CX) {
+                    const double a = FORM == 0 ? sf[0][s] : of[0][o], b = FORM == 0 ? of[0][o] : sf[0][s];
+                    acc[0][s][o] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, fresh ? zero : acc[0][s][o], 0, 0, 0);
+                } else {
+                    const double ar = FORM == 0 ? sf[0][s] : of[0][o], ai = FORM == 0 ? sf[1][s] : of[1][o];
+                    const double br = FORM == 0 ? of[0][o] : sf[0][s], bi = FORM == 0 ? of[1][o] : sf[1][s];
+                    acc[0][s][o] = __builtin_amdgcn_mfma_f64_16x16x4f64(ar, br, fresh ? zero : acc[0][s][o], 0, 0, 0);
+                    acc[1][s][o] = __builtin_amdgcn_mfma_f64_16x16x4f64(ar, bi, fresh ? zero : acc[1][s][o], 0, 0, 0);
+                    acc[0][s][o] = __builtin_amdgcn_mfma_f64_16x16x4f64(-ai, bi, acc[0][s][o], 0, 0, 0);
+                    acc[1][s][o] = __builtin_amdgcn_mfma_f64_16x16x4f64(ai, br, acc[1][s][o], 0, 0, 0);
+                }
+            }
+        }
     };
 
     // ---- the result leaves through buffer stores: SGPR descriptor (base advanced per row on the scalar ALU) + one 32-bit lane
-    // offset per block; lanes that must not store carry an offset past the descriptor's range and are dropped by the hardware.
-    // No VALU instruction and no branch per store, so the stores of a tile ride between the products of its LAST block of
-    // matrix instructions (LAG blocks behind) instead of following them with the matrix pipe idle.
-    // register r of a lane holds row (lane >> 4) + 4 r, column lane & 15 of a 16 x 16 block.
+    // offset per block; lanes that must not store carry an offset past the descriptor's range and are dropped by the hardware:
+    // no VALU instruction and no branch per store.  Register r of a lane holds row (lane >> 4) + 4 r, column lane & 15 of a
+    // 16 x 16 block.
     constexpr unsigned kDropped = 0xFFFFFFFFu, kRange = 0x80000000u;
     unsigned voff_c[WN];           // FORM 0: per tile; FORM 1: fixed (column block 0; later blocks through the immediate offset)
     unsigned voff_c_last = 0;      // FORM 1: the same for the last column block (columns >= n dropped)
     uint64_t c_base = 0;           // FORM 0: first segment of the tile;  FORM 1: first row of the wave in the tile
     if constexpr (FORM == 1) {
-        voff_c[0] = (unsigned)(((int64_t)(lane >> 4) * g.ldc + (lane & 15)) * 8);
+        voff_c[0] = (unsigned)(((int64_t)(lane >> 4) * g.ldc + (lane & 15)) * ESZ);
         voff_c_last = ((T - 1) * 16 + (lane & 15) < g.small) ? voff_c[0] : kDropped;
     }
     auto aim_stores = [&](unsigned v) __attribute__((always_inline)) {
@@ -269,31 +294,40 @@ void gemm_strip_kernel(const StripArgs g) {
         if constexpr (FORM == 0) {
             const unsigned W = (unsigned)g.Wp;
             const unsigned seg0 = __builtin_amdgcn_readfirstlane((unsigned)t0 / W);
-            c_base = uniform64(reinterpret_cast<uint64_t>(g.C + (int64_t)seg0 * g.sc));
+            c_base = uniform64(reinterpret_cast<uint64_t>(reinterpret_cast<char*>(g.C) + (int64_t)seg0 * g.sc * ESZ));
 #pragma unroll
             for (int o = 0; o < WN; ++o) {
                 const unsigned j = (unsigned)t0 + wave * 16 * WN + o * 16 + (lane & 15);
                 const unsigned sj = j / W;
                 const bool ok = j < (unsigned)g.big && j - sj * W < (unsigned)g.W;
-                voff_c[o] = ok ? (unsigned)(((int64_t)(sj - seg0) * g.sc + (j - sj * W) + (int64_t)(lane >> 4) * g.ldc) * 8) : kDropped;
+                voff_c[o] = ok ? (unsigned)(((int64_t)(sj - seg0) * g.sc + (j - sj * W) + (int64_t)(lane >> 4) * g.ldc) * ESZ) : kDropped;
             }
         } else {
-            c_base = uniform64(reinterpret_cast<uint64_t>(g.C + (t0 + wave * 16 * WN) * g.ldc));
+            c_base = uniform64(reinterpret_cast<uint64_t>(reinterpret_cast<char*>(g.C) + (t0 + wave * 16 * WN) * g.ldc * ESZ));
         }
     };
-    auto store_block = [&](int s, uint64_t ldc8) __attribute__((always_inline)) {
+    auto store_one = [&](int s, int o, int r, const auto& rsrc, unsigned off, int soff) __attribute__((always_inline)) {
+        const double re = acc[0][s][o][r];      // (a bit cast of a vector ELEMENT reads element 0: through scalars)
+        if constexpr (CX) {
+            const double im = acc[1][s][o][r];
+            const f64x2 v = {re, im};
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, v), rsrc, (int)off, soff, 2);
+        } else {
+            __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2_t, re), rsrc, (int)off, soff, 2);
+        }
+    };
+    auto store_block = [&](int s, uint64_t ldc_b) __attribute__((always_inline)) {
 #ifndef QS_STRIP_ABLATE_STORES
         if constexpr (FORM == 0) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const uint64_t base = uniform64(c_base) + (uint64_t)(s * 16 + 4 * r) * ldc8;
+                const uint64_t base = uniform64(c_base) + (uint64_t)(s * 16 + 4 * r) * ldc_b;
                 const auto rsrc = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void*>(base), (short)0, (int)kRange, 0x00020000);
 #pragma unroll
                 for (int o = 0; o < WN; ++o) {
                     unsigned off = voff_c[o];
                     if (s == T - 1) off = (s * 16 + 4 * r + (lane >> 4) < g.small) ? off : kDropped;      // (last row block only)
-                    const double val = acc[s][o][r];      // (a bit cast of a vector ELEMENT reads element 0: through a scalar)
-                    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2_t, val), rsrc, (int)off, 0, 2);
+                    store_one(s, o, r, rsrc, off, 0);
                 }
             }
         } else {
@@ -301,32 +335,18 @@ void gemm_strip_kernel(const StripArgs g) {
             for (int o = 0; o < WN; ++o) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const uint64_t base = uniform64(c_base) + (uint64_t)(o * 16 + 4 * r) * ldc8;
+                    // (the column block goes into the BASE, not into the instruction's scalar offset: a 16-byte store with a
+                    // REGISTER scalar offset gets no wait states from the compiler before its data registers are rewritten --
+                    // the complex form, whose (re, im) pairs are staged through one register quad, stored torn values)
+                    const uint64_t base = uniform64(c_base) + (uint64_t)(o * 16 + 4 * r) * ldc_b + (uint64_t)(s * 16) * ESZ;
                     // rows past the last one lie past the end of C: dropped by the range check
                     const auto rsrc = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void*>(base), (short)0,
                                                                         (int)bytes_left(g.c_end, base), 0x00020000);
-                    const unsigned off = (s == T - 1 ? voff_c_last : voff_c[0]);
-                    const double val = acc[s][o][r];
-                    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2_t, val), rsrc, (int)off, s * 128, 2);
+                    store_one(s, o, r, rsrc, s == T - 1 ? voff_c_last : voff_c[0], 0);
                 }
             }
         }
 #endif
-    };
-    // the FIRST block of a tile (fresh accumulators) carries the stores of the tile before it: the old values of block s leave,
-    // then the product of block s starts the new sum in the same registers -- whatever the position of a tile's last live
-    // block (K tails), the first one is always k-step 0 of its first stage
-    auto store_mfma_step = [&](const double (&sf)[T], const double (&of)[WN]) __attribute__((always_inline)) {
-        // (opaque per tile: the row offsets (16 s + 4 r) ldc are loop-invariant, and hoisted out of the kernel's main loop by
-        // the dozen they would not fit the scalar registers)
-        uint64_t ldc8 = (uint64_t)g.ldc * 8;
-        asm volatile("" : "+s"(ldc8));
-#pragma unroll
-        for (int s = 0; s < T; ++s) {
-            store_block(s, ldc8);
-            mfma_block(s, sf, of, std::true_type{});
-            __builtin_amdgcn_sched_barrier(0);
-        }
     };
 
     using B0 = std::integral_constant<int, 0>;
@@ -341,68 +361,56 @@ void gemm_strip_kernel(const StripArgs g) {
     fetch(B0{});                       // global stage 0
     stash(B0{}, B0{});
     __syncthreads();
-    double s0[T], s1[T], o0[WN], o1[WN];
+    double s0[NP][T], s1[NP][T], o0[NP][WN], o1[NP][WN];
     fetch(S1{});                       // stage 1
     if constexpr (SETS == 2) fetch(B0{});      // stage 2
     read_frags(B0{}, 0, s0, o0);
 
     unsigned c_v = blockIdx.x;
     int c_k = 0;
-    bool pending = false;      // a finished tile whose stores have not been issued yet
 
     // One global stage.  The LDS buffer the next stage goes into was last read before the PREVIOUS barrier, so it is free
     // from the start of this stage: the next stage is written (and the registers it leaves refilled from memory) right
-    // after the first block of MFMAs, two blocks ahead of the barrier.
+    // after the first block of MFMAs, ahead of the barrier.
     auto stage = [&](auto cur_c, int gs) __attribute__((always_inline)) {
         constexpr int cur = decltype(cur_c)::value;
         using NXT = std::integral_constant<int, cur ^ 1>;
         using NSET = std::integral_constant<int, SETS == 2 ? (cur ^ 1) : 0>;
         const bool has_next = gs + 1 < stages;
-        const bool last = c_k == nk - 1;                        // last stage of its tile
-        const int ks_live = last ? (k_tail + 3) / 4 : KS;
-        // k-step kk of this stage on fragments (sf, of)
-        auto step = [&](int kk, const double (&sf)[T], const double (&of)[WN]) __attribute__((always_inline)) {
-            if (kk == 0 && c_k == 0) {
-                if constexpr (kFuseStores) { if (pending) store_mfma_step(sf, of); else mfma_step(sf, of, T_{}); }
-                else mfma_step(sf, of, T_{});
-            } else if (kk < ks_live) {
-                mfma_step(sf, of, F_{});
-            }
-        };
+        const int ks_live = (c_k == nk - 1) ? (k_tail + 3) / 4 : KS;
         read_frags(cur_c, 1, s1, o1);
         __builtin_amdgcn_sched_barrier(0);
-        step(0, s0, o0);
+        if (c_k == 0) mfma_step(s0, o0, T_{}); else mfma_step(s0, o0, F_{});
         __builtin_amdgcn_sched_barrier(0);
-        if constexpr (kFuseStores) {
-            if (last) { aim_stores(c_v); pending = true; }      // where this tile's result goes (it leaves with the next tile's first block)
-        }
         stash(NXT{}, NSET{});                    // stage gs + 1 (behind the last stage: zeros, never read)
         __builtin_amdgcn_sched_barrier(0);
         fetch(NSET{});                           // stage gs + 3 (two register sets) / gs + 2 (one)
         __builtin_amdgcn_sched_barrier(0);
-        read_frags(cur_c, 2, s0, o0);
-        __builtin_amdgcn_sched_barrier(0);
-        step(1, s1, o1);
-        __builtin_amdgcn_sched_barrier(0);
-        read_frags(cur_c, 3, s1, o1);
-        __builtin_amdgcn_sched_barrier(0);
-        step(2, s0, o0);
-        __builtin_amdgcn_sched_barrier(0);
+        if constexpr (KS == 4) {
+            read_frags(cur_c, 2, s0, o0);
+            __builtin_amdgcn_sched_barrier(0);
+            if (1 < ks_live) mfma_step(s1, o1, F_{});
+            __builtin_amdgcn_sched_barrier(0);
+            read_frags(cur_c, 3, s1, o1);
+            __builtin_amdgcn_sched_barrier(0);
+            if (2 < ks_live) mfma_step(s0, o0, F_{});
+            __builtin_amdgcn_sched_barrier(0);
+        }
 #ifndef QS_STRIP_ABLATE_BARRIER   // development: no stage barrier (results wrong; what the barrier costs)
         __syncthreads();
 #endif
         if (has_next) read_frags(NXT{}, 0, s0, o0);
         __builtin_amdgcn_sched_barrier(0);
-        step(3, s1, o1);
+        if (KS - 1 < ks_live) mfma_step(s1, o1, F_{});
         __builtin_amdgcn_sched_barrier(0);
-        if (++c_k == nk) {
-            if constexpr (!kFuseStores) {      // the tile's result leaves behind its last block
-                aim_stores(c_v);
-                uint64_t ldc8 = (uint64_t)g.ldc * 8;
-                asm volatile("" : "+s"(ldc8));
+        if (++c_k == nk) {      // the tile's result leaves behind its last block
+            aim_stores(c_v);
+            // (opaque per tile: the row offsets (16 s + 4 r) ldc are loop-invariant, and hoisted out of the kernel's main loop
+            // by the dozen they would not fit the scalar registers)
+            uint64_t ldc_b = (uint64_t)g.ldc * ESZ;
+            asm volatile("" : "+s"(ldc_b));
 #pragma unroll
-                for (int s = 0; s < T; ++s) store_block(s, ldc8);
-            }
+            for (int s = 0; s < T; ++s) store_block(s, ldc_b);
             c_k = 0;
             c_v += P;
         }
@@ -412,33 +420,31 @@ void gemm_strip_kernel(const StripArgs g) {
         stage(B0{}, gs);
         if (gs + 1 < stages) stage(B1{}, gs + 1);
     }
-    if (pending) {      // the last tile of this workgroup
-        uint64_t ldc8 = (uint64_t)g.ldc * 8;
-        asm volatile("" : "+s"(ldc8));
-#pragma unroll
-        for (int s = 0; s < T; ++s) store_block(s, ldc8);
-    }
 }
 
 namespace {
 
 // relative rate of a strip tile against the 128 x 128 tile of qs_gemm_fast.hip (same units as its shape weights)
-inline double strip_weight(int t, bool wide) {
+inline double strip_weight(bool cx, int t, bool wide) {
     if (g_tune.gemm_strip_w > 0) return 0.01 * g_tune.gemm_strip_w;
+    // complex (against the 64 x 128 tile of the general kernel; same-box sweep profiles/r04_strip_c128_sweep.txt: at equal tile
+    // extents the general kernel's whole tiles stay ahead by 3-5 %: l = 96 60.5 against 57.7, l = 120 57.5 against 55.9 TFLOP/s)
+    if (cx) return t >= 8 ? 0.95 : t == 6 ? 0.96 : t >= 4 ? 1.0 : 0.85;
     // (same-box sweep, profiles/r04_strip_sweep.txt: at equal tile extents -- l = 120, T = 8 -- the strip tile runs at 0.99 of
     // the 128 x 128 edge-form tile)
     return (t >= 8 ? 1.0 : t >= 5 ? 0.95 : 0.80) * (wide ? 1.06 : 1.0);
 }
 
-template <int FORM, int T, int WN>
+template <bool CX, int FORM, int T, int WN>
 int launch_strip(StripArgs g, hipStream_t stream) {
     // two register sets of global data in flight where the registers allow it
-    constexpr int SETS = (T * WN <= 12) ? 2 : 1;
+    constexpr int SETS = ((CX ? 2 : 1) * T * WN <= 12) ? 2 : 1;
+    constexpr int KT = CX ? 8 : 16, NP = CX ? 2 : 1;
     constexpr int TILE = 128 * WN;
     constexpr int A_ROWS = FORM == 0 ? 16 * T : TILE;
     constexpr int NA = (A_ROWS + 63) / 64;
     constexpr int SB = FORM == 0 ? TILE + 16 : 16 * T + ((T & 1) ? 32 : 16);
-    const size_t lds = sizeof(double) * 2 * (size_t)(NA * 64 * 18 + 16 * SB);
+    const size_t lds = sizeof(double) * 2 * NP * (size_t)(NA * 64 * (KT + 2) + KT * SB);
     const int64_t tiles = cdiv(g.big, TILE);
     if (tiles * g.nk >= (int64_t(1) << 31)) return 1;
     g.total = (unsigned)tiles;
@@ -446,26 +452,39 @@ int launch_strip(StripArgs g, hipStream_t stream) {
     P -= P % 8;
     if (P < 8) P = 8;
     if (P > tiles) P = tiles;
-    auto kern = gemm_strip_kernel<FORM, T, WN, SETS>;
+    auto kern = gemm_strip_kernel<CX, FORM, T, WN, SETS>;
     static PerDeviceLds lds_opt_in;
     if (int rc = opt_in_dynamic_lds((const void*)kern, lds, lds_opt_in, "hipFuncSetAttribute(gemm_strip)")) return rc;
     hipLaunchKernelGGL(kern, dim3((unsigned)P), dim3(512), lds, stream, g);
-    note_dispatch("qs::gemm_strip_kernel<%d, %d, %d, %d>", FORM, T, WN, SETS);
+    note_dispatch("qs::gemm_strip_kernel<%s, %d, %d, %d, %d>", CX ? "true" : "false", FORM, T, WN, SETS);
     return launch_status("gemm_strip launch");
 }
 
 // wide: two blocks of 16 per wave along the big extent (tiles of 256): half the staging of the shared operand per product, where
-// the accumulators fit (T <= kWideMaxT) and the tile list is long enough to fill the chip
+// the accumulators fit (fp64: T <= kWideMaxT) and the tile list is long enough to fill the chip
 constexpr int kWideMaxT = 10;
+constexpr int kMaxT = 16, kMaxTComplex = 8;
 
 template <int FORM>
-int launch_strip_t(int t, bool wide, const StripArgs& g, hipStream_t stream) {
-    switch (t) {
+int launch_strip_t(bool cx, int t, bool wide, const StripArgs& g, hipStream_t stream) {
+    if (cx) {
+        switch (t) {
 #ifdef QS_DEV_FEW_SHAPES      // development / sanitizer builds of the HOST side
-        case 9: return wide ? launch_strip<FORM, 9, 2>(g, stream) : launch_strip<FORM, 9, 1>(g, stream);
+            case 5: return launch_strip<true, FORM, 5, 1>(g, stream);
 #else
-#define QS_STRIP(TT) case TT: return launch_strip<FORM, TT, 1>(g, stream);
-#define QS_STRIP_W(TT) case TT: return wide ? launch_strip<FORM, TT, 2>(g, stream) : launch_strip<FORM, TT, 1>(g, stream);
+#define QS_STRIP(TT) case TT: return launch_strip<true, FORM, TT, 1>(g, stream);
+            QS_STRIP(1) QS_STRIP(2) QS_STRIP(3) QS_STRIP(4) QS_STRIP(5) QS_STRIP(6) QS_STRIP(7) QS_STRIP(8)
+#undef QS_STRIP
+#endif
+            default: return 1;
+        }
+    }
+    switch (t) {
+#ifdef QS_DEV_FEW_SHAPES
+        case 9: return wide ? launch_strip<false, FORM, 9, 2>(g, stream) : launch_strip<false, FORM, 9, 1>(g, stream);
+#else
+#define QS_STRIP(TT) case TT: return launch_strip<false, FORM, TT, 1>(g, stream);
+#define QS_STRIP_W(TT) case TT: return wide ? launch_strip<false, FORM, TT, 2>(g, stream) : launch_strip<false, FORM, TT, 1>(g, stream);
         QS_STRIP_W(1) QS_STRIP_W(2) QS_STRIP_W(3) QS_STRIP_W(4) QS_STRIP_W(5) QS_STRIP_W(6) QS_STRIP_W(7) QS_STRIP_W(8)
         QS_STRIP_W(9) QS_STRIP_W(10) QS_STRIP(11) QS_STRIP(12) QS_STRIP(13) QS_STRIP(14) QS_STRIP(15) QS_STRIP(16)
 #undef QS_STRIP
@@ -483,55 +502,59 @@ int launch_strip_t(int t, bool wide, const StripArgs& g, hipStream_t stream) {
 int gemm_strip_try(int dtype, const double* A, const double* B, double* C, int64_t m, int64_t n, int64_t k, int64_t lda,
                    int64_t ldb, int64_t ldc, int64_t batch, int64_t sa, int64_t sb, int64_t sc, int accumulate,
                    double other_cost, hipStream_t stream) {
-    if (!g_tune.gemm_strip || dtype != QS_F64 || accumulate) return 1;
+    if (!g_tune.gemm_strip || accumulate) return 1;
     if (m <= 0 || n <= 0 || k <= 0 || batch <= 0 || k >= (int64_t(1) << 30)) return 1;
-    // which extent is the small one: A shared by the batch and m <= 256 -> tall tiles over virtual columns; otherwise one
-    // product with n <= 256 -> wide tiles over the rows
+    const bool cx = dtype == QS_C128;
+    const int64_t esz = cx ? 16 : 8;
+    const int max_small = 16 * (cx ? kMaxTComplex : kMaxT);
+    if (cx && (!aligned(A, 16) || !aligned(B, 16) || !aligned(C, 16))) return 1;
+    // which extent is the small one: A shared by the batch and m small -> tall tiles over virtual columns; otherwise one
+    // product with n small -> wide tiles over the rows
     int form;
-    if ((batch == 1 || sa == 0) && m <= 256 && (batch > 1 || n >= m)) form = 0;
-    else if (batch == 1 && n <= 256) form = 1;
+    if ((batch == 1 || sa == 0) && m <= max_small && (batch > 1 || n >= m)) form = 0;
+    else if (batch == 1 && n <= max_small) form = 1;
     else return 1;
     if (batch == 1) { sb = 0; sc = 0; }
     StripArgs g;
     g.A = A; g.B = B; g.C = C;
     g.lda = lda; g.ldb = ldb; g.ldc = ldc;
     g.sb = sb; g.sc = sc;
-    g.k = (int)k; g.nk = (int)cdiv(k, 16);
+    g.k = (int)k; g.nk = (int)cdiv(k, cx ? 8 : 16);
     int t;
     if (form == 0) {
-        // Lane offsets are 32-bit and unsigned: a tile's columns reach at most 128 / n + 1 segments past its first one.  (Columns
+        // Lane offsets are 32-bit and unsigned: a tile's columns reach at most 256 / n + 1 segments past its first one.  (Columns
         // past the last one of the last tile compute offsets of their own -- whatever they address is either inside the
         // operand or cut off by the range check of the buffer descriptor, and they are never stored.)
         if (sb < 0 || sc < 0 || lda < k || ldb < n || ldc < n) return 1;
-        if ((256 / n + 2) * sb * 8 + n * 8 >= (int64_t(1) << 32) - 65536 || 64 * lda * 8 >= (int64_t(1) << 31)) return 1;
-        if (((256 / n + 2) * sc + n + 4 * ldc) * 8 >= (int64_t(1) << 31)) return 1;      // store offsets stay below the descriptor's range
-        g.W = n; g.Wp = n + (n & 1);
+        if (((256 / n + 2) * sb + n) * esz >= (int64_t(1) << 32) - 65536 || 64 * lda * esz >= (int64_t(1) << 31)) return 1;
+        if (((256 / n + 2) * sc + n + 4 * ldc) * esz >= (int64_t(1) << 31)) return 1;      // store offsets stay below the descriptor's range
+        g.W = n; g.Wp = cx ? n : n + (n & 1);
         if (g.Wp * batch + 512 >= (int64_t(1) << 32)) return 1;      // the kernel's column arithmetic is 32-bit
         g.big = g.Wp * batch; g.small = (int)m;
         t = (int)cdiv(m, 16);
     } else {
         if (lda < k || ldb < n || ldc < n) return 1;
-        if (64 * lda * 8 >= (int64_t(1) << 31) || 16 * ldb * 8 + 4096 >= (int64_t(1) << 30) || 4 * ldc * 8 + 4096 >= (int64_t(1) << 31)) return 1;
+        if (64 * lda * esz >= (int64_t(1) << 31) || 16 * ldb * esz + 4096 >= (int64_t(1) << 30) || 4 * ldc * esz + 8192 >= (int64_t(1) << 31)) return 1;
         g.big = m; g.W = g.Wp = 0; g.small = (int)n;
         t = (int)cdiv(n, 16);
     }
-    g.a_end = reinterpret_cast<uint64_t>(A) + (uint64_t)(((m - 1) * lda + k) * 8);
-    g.b_end = reinterpret_cast<uint64_t>(B) + (uint64_t)(((batch - 1) * sb + (k - 1) * ldb + n) * 8);
-    g.c_end = reinterpret_cast<uint64_t>(C) + (uint64_t)(((batch - 1) * sc + (m - 1) * ldc + n) * 8);
+    g.a_end = reinterpret_cast<uint64_t>(A) + (uint64_t)(((m - 1) * lda + k) * esz);
+    g.b_end = reinterpret_cast<uint64_t>(B) + (uint64_t)(((batch - 1) * sb + (k - 1) * ldb + n) * esz);
+    g.c_end = reinterpret_cast<uint64_t>(C) + (uint64_t)(((batch - 1) * sc + (m - 1) * ldc + n) * esz);
     // wide tiles (256 of the big extent) where the accumulators fit and the list still fills the chip a few times over
     const double slots = device_cu_count();
     static const int wide_env = [] { const char* e = getenv("QS_STRIP_WIDE"); return e ? atoi(e) : -1; }();      // (tuning runs)
-    bool wide = t <= kWideMaxT && cdiv(g.big, 256) >= 4 * (int64_t)slots;
-    if (wide_env >= 0) wide = wide_env != 0 && t <= kWideMaxT;
+    bool wide = !cx && t <= kWideMaxT && cdiv(g.big, 256) >= 4 * (int64_t)slots;
+    if (wide_env >= 0) wide = !cx && wide_env != 0 && t <= kWideMaxT;
     const int64_t tiles = cdiv(g.big, wide ? 256 : 128);
     if (g_tune.gemm_strip == 1) {
         // estimated time: rounds of the tile list over the CUs (one eight-wave workgroup each = both slots of the other
         // kernels' two four-wave workgroups) x tile area / relative rate
         const double rounds = tiles > 8 * slots ? tiles / slots : ceil(tiles / slots);
-        const double cost = rounds * (16.0 * t) * (wide ? 256.0 : 128.0) / 2.0 / strip_weight(t, wide);
+        const double cost = rounds * (16.0 * t) * (wide ? 256.0 : 128.0) / 2.0 / strip_weight(cx, t, wide);
         if (!(cost < other_cost)) return 1;
     }
-    return form == 0 ? launch_strip_t<0>(t, wide, g, stream) : launch_strip_t<1>(t, wide, g, stream);
+    return form == 0 ? launch_strip_t<0>(cx, t, wide, g, stream) : launch_strip_t<1>(cx, t, wide, g, stream);
 }
 
 }  // namespace qs

@@ -642,6 +642,64 @@ def test_strip_kernels_vs_oracle_and_bit_identical_to_the_general_kernel(K, m, n
         K.tuning_reset()
 
 
+@pytest.mark.parametrize("m,n,k,batch", [
+    (66, 66, 66, 30), (80, 6400, 80, 3), (100, 100000, 100, 1), (127, 127, 127, 9), (128, 384, 128, 2), (112, 112 * 3, 112, 5),
+    (20, 300, 20, 5), (1, 7, 1, 3), (17, 33, 5, 2),
+    (30000, 66, 66, 1), (4097, 100, 100, 1), (2000, 97, 97, 1), (1500, 127, 127, 1), (1000, 128, 128, 1), (300, 7, 3, 1),
+])
+def test_complex_strip_kernels_vs_oracle_and_bit_identical_to_the_general_kernel(K, m, n, k, batch):
+    # the complex128 form of the strip kernels (re / im planes, four real matrix instructions per fragment pair in the order of
+    # the other complex kernels): bases of up to 128 complex orbitals -- every RandomBasisSet and every spin-doubled tensor
+    rng = np.random.default_rng(m + 3 * n + 5 * k + batch)
+    A = crand(rng, m, k)
+    B = crand(rng, batch, k, n) if batch > 1 else crand(rng, k, n)
+    ref = np.matmul(A, B)
+    try:
+        K.tuning_set("gemm_fast", 0)
+        K.tuning_set("gemm_strip", 0)
+        K.tuning_set("gemm_stream", 0)
+        K.tuning_set("gemm_skinny", 0)
+        general = host(K.matmul(dev(A), dev(B)))
+        assert "gemm_kernel<" in K.last_dispatch(), K.last_dispatch()
+        K.tuning_set("gemm_strip", 2)
+        got = host(K.matmul(dev(A), dev(B)))
+        ran = K.last_dispatch()
+        assert "gemm_strip_kernel<true, " in ran, ran
+        assert relerr(got, ref) <= 1e-13
+        assert np.array_equal(got, general)                # the same k-ordered sums: identical bits
+    finally:
+        K.tuning_reset()
+
+
+@pytest.mark.parametrize("L,M", [(66, 66), (72, 70), (80, 80), (100, 100), (91, 112), (127, 127)])
+def test_complex_transform_on_the_strip_kernels_equals_the_general_kernel(K, L, M):
+    g = torch.Generator(device="cuda:0").manual_seed(L + M)
+    u = torch.complex(torch.rand(L, L, L, L, dtype=torch.float64, device="cuda:0", generator=g),
+                      torch.rand(L, L, L, L, dtype=torch.float64, device="cuda:0", generator=g))
+    C = torch.complex(torch.randn(L, M, dtype=torch.float64, device="cuda:0", generator=g),
+                      torch.randn(L, M, dtype=torch.float64, device="cuda:0", generator=g)) / L**0.5
+    Ct = C.conj().T.contiguous()
+    try:
+        K.tuning_set("gemm_fast", 0)
+        K.tuning_set("gemm_strip", 0)
+        K.tuning_set("pair4c", 0)
+        gen = K.transform_two_body(u, C, Ct)
+        assert "gemm_strip" not in K.last_dispatch()
+        K.tuning_set("gemm_strip", 2)
+        got = K.transform_two_body(u, C, Ct)
+        ran = K.last_dispatch()
+        assert "gemm_strip_kernel<true, 1, " in ran and "gemm_strip_kernel<true, 0, " in ran and "gemm_kernel" not in ran, ran
+        assert torch.equal(got, gen)
+        K.tuning_reset()
+        assert torch.equal(K.transform_two_body(u, C, Ct), gen)        # whatever the automatic choice is: the same bits
+    finally:
+        K.tuning_reset()
+    x, y, z, w = (torch.randn(M, dtype=torch.float64, device="cuda:0", generator=g).to(torch.complex128) for _ in range(4))
+    lhs = torch.einsum("pqrs,p,q,r,s->", got, x, y, z, w)
+    rhs = torch.einsum("abcd,a,b,c,d->", u, Ct.T @ x, Ct.T @ y, C @ z, C @ w)
+    assert abs(lhs - rhs).item() <= 1e-10 * abs(rhs).item()
+
+
 def test_strip_kernels_keep_non_finite_values_in_their_rows_and_columns(K):
     # rows / columns beyond the small extent and k >= K multiply whatever the loads returned: nothing of it may reach a
     # stored element (selects on the K tail, never-stored blocks elsewhere)
@@ -686,7 +744,7 @@ def test_transform_on_the_strip_kernels_equals_the_general_kernel_and_the_oracle
         K.tuning_set("gemm_strip", 2)
         got = K.transform_two_body(ud, C, Ct)
         ran = K.last_dispatch()
-        assert "gemm_strip_kernel<1, " in ran and "gemm_strip_kernel<0, " in ran and "gemm_kernel" not in ran and "gemm_fast" not in ran, ran
+        assert "gemm_strip_kernel<false, 1, " in ran and "gemm_strip_kernel<false, 0, " in ran and "gemm_kernel" not in ran and "gemm_fast" not in ran, ran
         assert torch.equal(got, gen)
         K.tuning_reset()
         auto = K.transform_two_body(ud, C, Ct)              # whatever the automatic choice is: the same bits
