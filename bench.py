@@ -104,7 +104,9 @@ def parse(argv=None):
     ap.add_argument("--staging-rows", type=int, default=1, help="rows per all-to-all of the in-place exchange")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-l", type=int, default=192, help="largest size of the CPU-baseline sample")
-    ap.add_argument("--cpu-full", action="store_true", help="also time the CPU baseline at the full l (one repetition)")
+    ap.add_argument("--cpu-full", choices=["auto", "on", "off"], default="auto", nargs="?", const="on",
+                    help="time the CPU baseline at the FULL l too (one repetition, ~100 s and ~105 GB of host memory at l = 256): "
+                         "auto = when the host has >= 110 GB available (SURVEY 8d)")
     ap.add_argument("--no-probes", action="store_true")
     ap.add_argument("--workload", choices=["transform", "spin_expand", "antisymmetrize"], default="transform",
                     help="transform = the headline metric; the other two are the HBM-bound kernels of "
@@ -439,6 +441,17 @@ def identity_parts_rows(torch, u_rows, out_rows, C, Ct, a_lo, q_lo, seed=7):
 # CPU baseline (the oracle, timed on the host cores of this box)
 # ----------------------------------------------------------------------------------------------
 
+def host_mem_available():
+    try:
+        with open("/proc/meminfo") as f:
+            for ln in f:
+                if ln.startswith("MemAvailable:"):
+                    return int(ln.split()[1]) * 1024
+    except OSError:
+        pass
+    return 0
+
+
 def cpu_baseline(l_max, budget_s=15.0, full_l=None):
     """The oracle (NumPy restatement of basis_set.py:341-348: tensordot x4) on the host cores of this box on
     a bounded sample of the same workload.  Fixed points at l=55 (BASELINE.json configs[1]) and l=128 with the
@@ -460,6 +473,10 @@ def cpu_baseline(l_max, budget_s=15.0, full_l=None):
 
     def inputs(l):
         rng = np.random.default_rng(0)
+        if l >= 200:      # the full workload: 34 GB at l = 256 -- a repeated random block (the time does not depend on the values),
+            u = np.resize(rng.random(1 << 22), (l, l, l, l))      # no symmetrised copy (three tensors of host memory less)
+            C, _ = np.linalg.qr(rng.standard_normal((l, l)))
+            return u, C
         u = rng.random((l, l, l, l))
         u = 0.5 * (u + u.transpose(1, 0, 3, 2))
         C, _ = np.linalg.qr(rng.standard_normal((l, l)))
@@ -489,6 +506,8 @@ def cpu_baseline(l_max, budget_s=15.0, full_l=None):
             points.append({"l": lp, "tensordot_x4_s": dt, "tensordot_x4_tflops": fl / dt / 1e12,
                            "einsum_optimize_s": dte, "einsum_optimize_tflops": fl / dte / 1e12})
     l, dt = (points[-1]["l"], points[-1]["tensordot_x4_s"]) if points else (48, run(48)[0])
+    if full_l and full_l > l:                 # the workload itself, one repetition (instead of the grown sample)
+        l, dt = full_l, run(full_l)[0]
     while dt < 0.6 * budget_s and l < l_max:  # grow the sample until it is worth 10-20 s
         nxt = int(min(l_max, max(l + 16, l * (budget_s / max(dt, 1e-3)) ** 0.2)))
         nxt -= nxt % 8
@@ -499,15 +518,14 @@ def cpu_baseline(l_max, budget_s=15.0, full_l=None):
     res = {
         "value": flops / dt / 1e12, "unit": "TFLOP/s", "cores": int(threads), "kind": "port",
         "sample": f"one fp64 transform at l={l} ({flops/1e9:.1f} GFLOP, {dt:.1f} s), numpy "
-                  f"{np.__version__} tensordot x4 (oracle/qs_oracle.py) on {blas} with {threads} threads "
+                  f"{np.__version__} tensordot x4 (oracle/qs_oracle.py"
+                  + (", the FULL workload, one repetition" if full_l and l == full_l else "") + f") on {blas} with {threads} threads "
                   f"(os.cpu_count={os.cpu_count()}); fixed points at l=55 and l=128 with "
                   f"numpy.einsum(optimize=True) beside them in `points`",
         "points": points,
     }
     if full_l:
-        dtf, _ = run(full_l)
-        ff = orc.transform_flops(full_l, full_l)
-        res["full_size"] = {"l": full_l, "tensordot_x4_s": dtf, "tensordot_x4_tflops": ff / dtf / 1e12}
+        res["full_size"] = {"l": l, "tensordot_x4_s": dt, "tensordot_x4_tflops": flops / dt / 1e12}
     return res
 
 
@@ -1010,7 +1028,9 @@ def run_rank(args):
                                                "p-sharded result on every GPU (north star's single collective)"}
     if not args.no_cpu_baseline and world == 1:   # reported at N = 1 only (rank 0 would stall the others)
         del res, rows
-        line["cpu_baseline"] = cpu_baseline(args.cpu_l, full_l=l if args.cpu_full else None)
+        full = args.cpu_full == "on" or (args.cpu_full == "auto" and args.dtype == "f64" and 4.2 * 8 * l**4 < 0.9 * host_mem_available()
+                                         and host_mem_available() >= 110e9 and l >= 200)
+        line["cpu_baseline"] = cpu_baseline(args.cpu_l, full_l=l if full else None)
     print(json.dumps(line), flush=True)
     if use_dist:
         dist.barrier()

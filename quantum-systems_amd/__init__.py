@@ -14,7 +14,7 @@ import it as ``quantum_systems_amd`` (the sibling shim package aliases it).
 from . import _lib, kernels, sharded  # noqa: F401
 from .array_module import DeviceArray, DeviceModule, hip
 from .sharded_module import ShardedDeviceModule, ShardedTensor4
-from .basis_set import BasisSet
+from .basis_set import BasisSet, ChangeBasisPlan
 from .custom_system import construct_custom_system, setup_basis_set
 from .general_orbital_system import GeneralOrbitalSystem
 from .one_dim_qd import ODQD
@@ -28,5 +28,5 @@ __all__ = [
     "BasisSet", "RandomBasisSet", "QuantumSystem", "SpatialOrbitalSystem",
     "GeneralOrbitalSystem", "setup_basis_set", "construct_custom_system",
     "TwoDimensionalHarmonicOscillator", "TwoDimensionalDoubleWell", "TwoDimHarmonicOscB", "ODQD", "ODSincDVR",
-    "hip", "DeviceModule", "DeviceArray", "ShardedDeviceModule", "ShardedTensor4", "kernels", "sharded",
+    "ChangeBasisPlan", "hip", "DeviceModule", "DeviceArray", "ShardedDeviceModule", "ShardedTensor4", "kernels", "sharded",
 ]

@@ -494,6 +494,12 @@ class BasisSet:
             self.bra_spf = bra
             self.spf = ket
 
+    def change_basis_plan(self, C_tilde_given=False):
+        """``change_basis`` with a SQUARE coefficient matrix, captured once as a HIP graph (``ChangeBasisPlan``): for loops
+        that rotate a small basis again and again (orbital optimisation; :413-464 every iteration), where the Python and
+        launch side of a call costs several times its kernels."""
+        return ChangeBasisPlan(self, C_tilde_given)
+
     def compute_particle_density(self, rho_qp, C=None, C_tilde=None):
         """rho(r) = bra_q(r) rho_qp ket_p(r), optionally in a rotated basis
         (:466-509)."""
@@ -706,3 +712,132 @@ class BasisSet:
     @staticmethod
     def check_axis_lengths(arr, length):
         return [length == axis for axis in arr.shape]
+
+
+class ChangeBasisPlan:
+    """``BasisSet.change_basis(C)`` for a SQUARE ``C`` on the device array module, captured once as a HIP graph.
+
+    Below ~32 orbitals a change of basis is a handful of 5-10 us kernels while the Python side of ``change_basis`` (staging,
+    wrapping, ctypes, allocator, setters) costs ~55 us (profiles/r03_api_overhead.txt).  The plan does that work ONCE: the
+    stacked one-body call (h, s, position, momentum), the two-body call (u) and the transform of the spin_2_tb recipe are
+    captured on buffers the plan owns -- two sets of them, so that the arrays of call n are the input of call n + 1 --
+    and a call is: copy ``C`` into the plan's coefficient buffer, replay, rebind the attributes.
+
+        plan = basis.change_basis_plan()
+        for it in range(n):
+            plan(C_it)                      # == basis.change_basis(C_it): the same kernels, the same bits
+
+    What differs from ``change_basis``: the arrays handed out by call n are overwritten by call n + 2 (keep a ``.copy()`` of
+    what must live longer); ``C`` must be (l, l); single-particle functions are not carried (``spf`` must be None); the
+    dtype of the arrays is fixed at planning time (complex ``C`` needs complex arrays: promote before planning).
+    ``C_tilde_given=True`` captures the form with explicit bra coefficients: ``plan(C, C_tilde)``."""
+
+    def __init__(self, basis, C_tilde_given=False):
+        from . import _lib
+
+        if not is_device_module(basis.np) or is_sharded_module(basis.np):
+            raise NotImplementedError("ChangeBasisPlan: device array module only")
+        if basis.spf is not None:
+            raise NotImplementedError("ChangeBasisPlan does not carry single-particle functions: use change_basis")
+        if basis._spin_2_tb is not None and not basis._spin_2_tb_recipe_valid():
+            raise NotImplementedError("ChangeBasisPlan: spin_2_tb is held as a tensor somebody wrote into: use change_basis")
+        lib = _lib.load()
+        self.basis, self.l, self.explicit_bra = basis, basis.l, bool(C_tilde_given)
+        l = basis.l
+        u = _stage(basis.u).as_subclass(torch.Tensor)
+        dt = u.dtype
+        self.dtype = dt
+        names = [k for k in ("h", "s", "position", "momentum") if getattr(basis, k) is not None]
+        mats = [_stage(getattr(basis, k)).as_subclass(torch.Tensor) for k in names]
+        if any(m.dtype != dt or tuple(m.shape[-2:]) != (l, l) for m in mats) or tuple(u.shape) != (l, l, l, l):
+            raise NotImplementedError("ChangeBasisPlan: h, s, position, momentum and u of one dtype and one basis size")
+        recipe = basis._spin_2_tb_recipe if basis._spin_2_tb_recipe_valid() else None
+        if recipe is not None:
+            rstack = _stage(recipe[0]).as_subclass(torch.Tensor)
+            if rstack.dtype != dt:
+                raise NotImplementedError("ChangeBasisPlan: the spin matrices of the spin_2_tb recipe in the basis set's dtype")
+            mats.append(rstack)
+            names.append("__recipe")
+        counts = [m.numel() // (l * l) for m in mats]
+        nmat = sum(counts)
+        dev = u.device
+        code = kernels.dtype_code(dt)
+        es = 16 if dt.is_complex else 8
+        self.C = torch.empty((l, l), dtype=dt, device=dev)
+        self.Ct = torch.empty((l, l), dtype=dt, device=dev)
+        self._pile = [torch.empty((nmat, l, l), dtype=dt, device=dev) for _ in range(2)]
+        self._u = [torch.empty((l, l, l, l), dtype=dt, device=dev) for _ in range(2)]
+        self._pile[0].copy_(torch.cat([m.reshape(-1, l, l) for m in mats]))
+        self._u[0].copy_(u)
+        w2 = kernels.check(lib.qs_transform_two_body_workspace(code, l, l), "workspace query")
+        self._work = torch.empty(int(max(w2, nmat * l * l * es)) + 64, dtype=torch.uint8, device=dev)
+        # the arrays the basis set is handed, per buffer set (wrapped once)
+        self._views = []
+        for k in range(2):
+            v, at = {}, 0
+            for name, m, cnt in zip(names, mats, counts):
+                part = self._pile[k][at] if m.dim() == 2 else self._pile[k][at:at + cnt].reshape(m.shape)
+                v[name] = wrap(part)
+                at += cnt
+            v["u"] = wrap(self._u[k])
+            self._views.append(v)
+        self._anti = recipe[1] if recipe is not None else None
+        stream = kernels._stream
+
+        def launch(src, dst):
+            if not self.explicit_bra:
+                torch.conj_physical(self.C.transpose(0, 1), out=self.Ct) if dt.is_complex else self.Ct.copy_(self.C.transpose(0, 1))
+            kernels._ran(lib.qs_transform_one_body(code, self._pile[src].data_ptr(), self.C.data_ptr(), self.Ct.data_ptr(),
+                                                   self._pile[dst].data_ptr(), self._work.data_ptr(), self._work.numel(),
+                                                   nmat, l, l, stream()), "qs_transform_one_body")
+            kernels._ran(lib.qs_transform_two_body(code, self._u[src].data_ptr(), self.C.data_ptr(), self.Ct.data_ptr(),
+                                                   self._u[dst].data_ptr(), self._work.data_ptr(), self._work.numel(), l, l,
+                                                   stream()), "qs_transform_two_body")
+
+        if dev.index != torch.cuda.current_device():
+            raise ValueError("ChangeBasisPlan: make the device that owns the basis set current first (torch.cuda.device)")
+        self.C.copy_(torch.eye(l, dtype=dt, device=dev))
+        self.Ct.copy_(self.C)
+        keep = (self._pile[0].clone(), self._u[0].clone())
+        side = torch.cuda.Stream(device=dev)
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            launch(0, 1)                                  # first-launch set-up outside the capture
+        torch.cuda.current_stream().wait_stream(side)
+        self._graphs = []
+        for src in (0, 1):
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                launch(src, src ^ 1)
+            self._graphs.append(g)
+        self._pile[0].copy_(keep[0])
+        self._u[0].copy_(keep[1])
+        self._cur = 0
+        self._bind(0)
+
+    def _bind(self, k):
+        b, v = self.basis, self._views[k]
+        with torch._C.DisableTorchFunctionSubclass():
+            b._h = v["h"]
+            if "s" in v:
+                b._s = v["s"]
+            if "position" in v:
+                b._position = v["position"]
+            if "momentum" in v:
+                b._momentum = v["momentum"]
+            b._u = v["u"]
+            if "__recipe" in v:
+                b._spin_2_tb = None
+                b._spin_2_tb_recipe = (v["__recipe"], self._anti)
+
+    def __call__(self, C, C_tilde=None):
+        if (C_tilde is not None) != self.explicit_bra:
+            raise ValueError("this plan was captured " + ("with" if self.explicit_bra else "without") + " explicit bra coefficients")
+        with torch._C.DisableTorchFunctionSubclass():
+            self.C.copy_(C)                               # (shape and dtype checked by copy_)
+            if self.explicit_bra:
+                self.Ct.copy_(C_tilde)
+            self._graphs[self._cur].replay()
+        self._cur ^= 1
+        self._bind(self._cur)
+        return self.basis

@@ -53,6 +53,11 @@ class QuantumSystem(metaclass=abc.ABCMeta):
         self._basis_set.change_basis(C, C_tilde)
         self.set_system_size(self.n, self._basis_set.l)
 
+    def change_basis_plan(self, C_tilde_given=False):
+        """``change_basis`` with a square ``C`` captured as a HIP graph (``basis_set.ChangeBasisPlan``): ``plan(C)`` instead of
+        ``system.change_basis(C)`` in loops over a small basis; ``n``, ``l``, ``o`` and ``v`` do not change."""
+        return self._basis_set.change_basis_plan(C_tilde_given)
+
     def transform_one_body_elements(self, h, C, C_tilde=None):
         return self._basis_set.transform_one_body_elements(h, C, np=self.np, C_tilde=C_tilde)
 

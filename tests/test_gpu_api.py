@@ -495,3 +495,46 @@ def test_inplace_transform_kernel_wrapper():
     with pytest.raises(ValueError):
         K.transform_two_body_(torch.zeros((4,) * 4, dtype=torch.float64, device="cuda"),
                               torch.zeros((4, 6), dtype=torch.float64, device="cuda"))      # growing basis
+
+
+@pytest.mark.parametrize("l,spin", [(12, False), (20, False), (6, True)])
+def test_change_basis_plan_replays_change_basis_bit_for_bit(l, spin):
+    # round 4: change_basis with a square C captured as a HIP graph (two buffer sets, a call = copy C + one replay + rebinding
+    # the attributes): the same kernels as change_basis, so the same bits -- h, s, position, u, and on a spin-doubled basis
+    # the spin_2_tb recipe; explicit bra coefficients as a second captured form
+    np.random.seed(11)
+    make = (lambda: SpatialOrbitalSystem(2, RandomBasisSet(l, 2))) if not spin else \
+        (lambda: SpatialOrbitalSystem(2, RandomBasisSet(l, 2)).construct_general_orbital_system())
+    state = np.random.get_state()
+    a = make()
+    np.random.set_state(state)
+    b = make()
+    a.change_module(hip)
+    b.change_module(hip)
+    n = a.l
+    rng = np.random.default_rng(5)
+    Cs = [np.linalg.qr(rng.standard_normal((n, n)) + 1j * rng.standard_normal((n, n)))[0] for _ in range(4)]
+    Cs = [torch.from_numpy(c).cuda() for c in Cs]
+    plan = b.change_basis_plan()
+    for c in Cs[:3]:
+        a.change_basis(c)
+        assert plan(c) is b._basis_set
+        for name in ("h", "s", "u", "position"):
+            assert torch.equal(torch.as_tensor(getattr(a, name)), torch.as_tensor(getattr(b, name))), name
+    if spin:
+        assert torch.equal(torch.as_tensor(a.spin_2_tb), torch.as_tensor(b.spin_2_tb))
+        assert torch.equal(torch.as_tensor(a.spin_x), torch.as_tensor(b.spin_x))      # (left alone by both, quirk 0.6)
+    assert abs(complex(H(a.compute_reference_energy())) - complex(H(b.compute_reference_energy()))) == 0
+    # explicit bra coefficients
+    Ct = torch.linalg.inv(Cs[3])
+    plan2 = b.change_basis_plan(C_tilde_given=True)
+    a.change_basis(Cs[3], C_tilde=Ct)
+    plan2(Cs[3], Ct)
+    for name in ("h", "s", "u", "position"):
+        assert torch.equal(torch.as_tensor(getattr(a, name)), torch.as_tensor(getattr(b, name))), name
+    with pytest.raises(ValueError):
+        plan2(Cs[3])
+    # what a plan does not do
+    rect = torch.from_numpy(rng.standard_normal((n, n - 1))).cuda()
+    with pytest.raises(RuntimeError):
+        plan(rect.to(torch.complex128))

@@ -317,7 +317,10 @@ def test_spin_squared_two_body_golden(K, golden):
 @pytest.mark.parametrize("cplx", [False, True])
 @pytest.mark.parametrize(
     "L,M",
-    [(1, 1), (2, 3), (5, 5), (16, 16), (17, 13), (20, 20), (10, 18), (33, 32), (55, 55), (64, 64), (70, 40)],
+    [(1, 1), (2, 3), (5, 5), (16, 16), (17, 13), (20, 20), (10, 18), (33, 32), (55, 55), (64, 64), (70, 40),
+     # the automatic route above 70 orbitals, directly against the oracle (VERDICT r03 "next" 6): the streamed kernel with two
+     # workgroups per item quad (fp64 65-95), the strip kernels (fp64 from 96, complex128 65-128), rectangular C
+     (78, 78), (91, 91), (96, 93), (84, 81), (100, 100), (113, 97)],
 )
 def test_transform_vs_oracle(K, L, M, cplx):
     rng = np.random.default_rng(1000 * L + M + cplx)

@@ -32,7 +32,18 @@ for _ in range(n):
     bs.change_basis(C)
 torch.cuda.synchronize()
 t_api = (time.perf_counter() - t0) / n
-ut = torch.as_tensor(bs.u)
+t_plan = None
+if getattr(bs, "spf", None) is None:
+    plan = bs.change_basis_plan()
+    for _ in range(3):
+        plan(C)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(n):
+        plan(C)
+    torch.cuda.synchronize()
+    t_plan = (time.perf_counter() - t0) / n
+ut = torch.as_tensor(bs.u).clone()
 Ct = C.conj().T.contiguous()
 out = torch.empty_like(ut)
 for _ in range(3):
@@ -43,5 +54,6 @@ for _ in range(n):
     K.transform_two_body(ut, C, Ct, out=out)
 torch.cuda.synchronize()
 t_k = (time.perf_counter() - t0) / n
-print(f"{kind} l={l} ({ut.dtype}): setup {t_setup:.2f} s; change_basis {t_api * 1e6:.0f} us per call; the two-body "
+print(f"{kind} l={l} ({ut.dtype}): setup {t_setup:.2f} s; change_basis {t_api * 1e6:.0f} us per call; "
+      + (f"ChangeBasisPlan {t_plan * 1e6:.0f} us per call; " if t_plan is not None else "") + "the two-body "
       f"transform alone {t_k * 1e6:.0f} us | {K.last_dispatch()}")
