@@ -89,7 +89,20 @@ void gemm_fast_kernel(const FastArgs g) {
     constexpr int BM = 32 * TM, BN = 32 * TN;
     // B rows: complex fragments are ds_read_b64 (row stride = 16 mod 32 doubles is conflict-free);
     // fp64 fragments are ds_read_b128 column PAIRS (row stride = 0 mod 32 is conflict-free)
-    constexpr int SA = KT + 2, SB = CX ? BN + 16 : BN;
+    // A rows: fp64 pads the row to KT + 2 (stride 18: conflict-free fragment reads, tolerable writes).  complex128 (round 4): no
+    // padding, the k index of a row XOR-ed with 2 ((row >> 2) & 3) instead -- a half wave of the stage WRITE (four rows x eight
+    // k) then covers 32 different bank pairs, and so does a half wave of the fragment READ (sixteen rows x two k): with the
+    // padded rows of rounds 1-3 (stride 10) writes of the A stage collided.  Measured (profiles/r04_pmc_c128.txt, same-box A/B
+    // r04_c128_swizzle_ab.txt): SQ_LDS_BANK_CONFLICT 40 -> 31 % and 25 -> 18 % of the LDS-active cycles of the two tile forms,
+    // l = 256 66.9 -> 67.5, l = 128 64.2 -> 64.6 TFLOP/s.  What is left scales with the number of A-stage writes (8 conflict
+    // cycles per write instruction in both forms): the lanes a 64-bit LDS write serves together are not the half waves assumed
+    // here -- open.
+#ifdef QS_FAST_CX_PAD      // (A/B builds: the padded complex rows of rounds 1-3)
+    constexpr bool kSwizzleA = false;
+#else
+    constexpr bool kSwizzleA = CX;
+#endif
+    constexpr int SA = kSwizzleA ? KT : KT + 2, SB = CX ? BN + 16 : BN;      // (B rows 8 mod 16 instead of 16 mod 32: measured, level)
     constexpr int EPI = (!CX && VEC) ? 2 : 1;           // tensor elements per global item
     constexpr int DPI = CX ? 1 : EPI;                   // doubles per item inside one LDS plane
     constexpr int IPR_A = KT / EPI;                     // items per A row of a stage
@@ -170,9 +183,14 @@ void gemm_fast_kernel(const FastArgs g) {
     const size_t b_step = (size_t)KT * g.ldb * ESZ;
 
     // ---- LDS addressing: one base per operand and direction, the rest immediates
-    double* st_a = As + (tid / IPR_A) * SA + (tid % IPR_A) * DPI;
+    double* st_a = kSwizzleA ? As + (tid / IPR_A) * SA + ((tid % IPR_A) ^ (2 * (((tid / IPR_A) >> 2) & 3)))
+                             : As + (tid / IPR_A) * SA + (tid % IPR_A) * DPI;
     double* st_b = Bs + (tid / IPR_B) * SB + (tid % IPR_B) * DPI;
     const double* rd_a = As + (wm * 16 * TM + (lane & 15)) * SA + (lane >> 4);
+    // complex: the swizzled position of k = 4 kk + (lane >> 4) depends on kk -- one base per k-step of a stage (KS = 2)
+    const int swz_r = kSwizzleA ? 2 * (((lane & 15) >> 2) & 3) : 0;
+    const double* rd_a_cx[2] = {As + (wm * 16 * TM + (lane & 15)) * SA + ((lane >> 4) ^ swz_r),
+                                As + (wm * 16 * TM + (lane & 15)) * SA + ((4 + (lane >> 4)) ^ swz_r)};
     // fp64: lane c of n-tile pair (2jp, 2jp+1) owns the ADJACENT columns 32jp + 2c, 32jp + 2c + 1,
     // so one 16-byte LDS read feeds two MFMA tiles and the epilogue stores 16 bytes per lane
     const double* rd_b = Bs + (lane >> 4) * SB + wn * 16 * TN + (CX ? 1 : 2) * (lane & 15);
@@ -247,7 +265,7 @@ void gemm_fast_kernel(const FastArgs g) {
 
     auto read_frags = [&](auto buf_c, int kk, double (&af)[NP][TM], double (&bf)[NP][TN]) {
         constexpr int buf = decltype(buf_c)::value;
-        const double* as = rd_a + buf * A_STAGE;
+        const double* as = (CX ? rd_a_cx[kk & 1] - kk * 4 : rd_a) + buf * A_STAGE;
         const double* bs = rd_b + buf * B_STAGE;
 #pragma unroll
         for (int p = 0; p < NP; ++p) {
@@ -469,7 +487,11 @@ static int launch_fast(const double* A, const double* B, double* C, int64_t m, i
         P = (P + 7) & ~int64_t(7);
     }
     if (P > total) P = total;
+#if defined(QS_FAST_CX_PAD)
     const size_t lds = sizeof(double) * 2 * NP * (BM * (KT + 2) + KT * (CX ? BN + 16 : BN));
+#else
+    const size_t lds = sizeof(double) * 2 * NP * (BM * (CX ? KT : KT + 2) + KT * (CX ? BN + 16 : BN));
+#endif
     auto kern = gemm_fast_kernel<CX, TM, TN, VEC, EDGE>;
     static PerDeviceLds lds_opt_in;   // per instantiation and per device
     if (int rc = opt_in_dynamic_lds((const void*)kern, lds, lds_opt_in, "hipFuncSetAttribute(gemm_fast)")) return rc;
