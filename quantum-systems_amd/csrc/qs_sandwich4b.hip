@@ -126,8 +126,16 @@ __global__ __launch_bounds__(256, 1) void sandwich4b_kernel(const S4Args g) {
         const uint64_t p = reinterpret_cast<uint64_t>(base + (int64_t)quad * 4 * item_stride);
         const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)p);
         const uint32_t hi = __builtin_amdgcn_readfirstlane((uint32_t)(p >> 32));
-        return __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void*>(((uint64_t)hi << 32) | lo), (short)0,
-                                                 0x7fffffff, 0x00020000);
+        // (development, round 4: -DQS_S4B_ABLATE_LOADS / _STORES give the tensor's descriptors a zero range -- loads answer with
+        // zeros and stores are dropped without touching memory: the kernel's skeleton, profiles/r04_small_basis_bound.txt)
+        int range = 0x7fffffff;
+#ifdef QS_S4B_ABLATE_LOADS
+        if (base == g.in - 1) range = 0;
+#endif
+#ifdef QS_S4B_ABLATE_STORES
+        if (base == g.out) range = 0;
+#endif
+        return __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void*>(((uint64_t)hi << 32) | lo), (short)0, range, 0x00020000);
     };
     // Fetch layout of a fragment pair (qs_sandwich4.hip): lane = h + 4 row + 16 item; k = 8 m + 2 h, 2 h + 1 -- 16 bytes
     // per lane, 64-byte runs; fragment 2 m + (h >> 1).
