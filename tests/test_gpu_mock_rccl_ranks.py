@@ -68,7 +68,7 @@ def test_bench_rccl_legs_with_two_ranks_over_the_stand_in(built):
     import sys
 
     d, _ = built
-    for layout in ("rows_rccl", "rccl"):
+    for layout in ("rows_rccl", "rows_rccl_coalesced", "rccl"):
         run_dir = d / f"bench_{layout}"
         run_dir.mkdir()
         env = dict(os.environ, QS_BENCH_SINGLE_DEVICE="1", QS_BENCH_BACKEND="gloo", MASTER_ADDR="127.0.0.1",
@@ -82,6 +82,7 @@ def test_bench_rccl_legs_with_two_ranks_over_the_stand_in(built):
         line = json.loads([ln for ln in res.stdout.splitlines() if ln.strip().startswith("{")][0])
         assert line["n_gpus"] == 2 and line["n_ranks_seen"] == 2 and line["parity"]["ok"] is True
         assert "rccl grouped send/recv" in line["roofline"]["dispatch"]
+        assert ("one message per peer and step" in line["roofline"]["dispatch"]) == (layout == "rows_rccl_coalesced")
 
 
 def test_sharded_module_through_the_c_entry_with_three_ranks(built):
