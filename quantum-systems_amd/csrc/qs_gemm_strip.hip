@@ -52,6 +52,9 @@ struct StripArgs {
     int small;               // FORM 0: rows m (of A and of the result);  FORM 1: columns n
     int k, nk;               // K, ceil(K / KT)
     unsigned total;          // tiles
+    int nsmall;              // tiles along the SMALL extent (1: the whole of it in one tile of 16 T; up to 4 for extents beyond
+                             // 16 T: virtual block w = tile w % nsmall of the small extent, tile w / nsmall of the big one -- the
+                             // tiles that share a piece of the streamed operand are neighbours on one XCD and meet in its L2)
 };
 
 // CX = complex128 (re / im planes in LDS, four real matrix instructions per fragment pair in the order of the other tiled kernels:
@@ -105,12 +108,20 @@ void gemm_strip_kernel(const StripArgs g) {
     bool f_valid = true;
     const unsigned voff_a = (unsigned)(tid / IPR_A) * (unsigned)g.lda * ESZ + (unsigned)(tid % IPR_A) * IB;
     // start of tile w of the big extent
-    auto tile_start = [&](unsigned v) -> int64_t {
-        const unsigned w = xcd_chunked_index_fast(v, g.total);
-        return (int64_t)__builtin_amdgcn_readfirstlane((int)w) * TILE;
+    // start of virtual block v along the big extent, and (s0) along the small one
+    auto tile_start = [&](unsigned v, int& s0) -> int64_t {
+        unsigned w = __builtin_amdgcn_readfirstlane(xcd_chunked_index_fast(v, g.total));
+        s0 = 0;
+        if (g.nsmall > 1) {
+            const unsigned b = __builtin_amdgcn_readfirstlane(w / (unsigned)g.nsmall);
+            s0 = (int)(w - b * (unsigned)g.nsmall) * 16 * T;
+            w = b;
+        }
+        return (int64_t)w * TILE;
     };
     auto aim = [&](unsigned v) __attribute__((always_inline)) {
-        const int64_t t0 = tile_start(v);
+        int s0;
+        const int64_t t0 = tile_start(v, s0);
         if constexpr (FORM == 0) {
             // virtual column j -> element (j / Wp) * sb + j % Wp of its B row; the tile's first segment goes into the scalar base
             // (32-bit divisions: the host admits big + 512 < 2^32 only)
@@ -125,12 +136,12 @@ void gemm_strip_kernel(const StripArgs g) {
                 b_ptr[i] = uniform64(reinterpret_cast<uint64_t>(Bb + (size_t)(wave * 64 / IPR_B + i * RPS) * g.ldb * ESZ));
 #pragma unroll
             for (int i = 0; i < NA; ++i)
-                a_ptr[i] = uniform64(reinterpret_cast<uint64_t>(reinterpret_cast<const char*>(g.A) + (size_t)i * RA * g.lda * ESZ));
+                a_ptr[i] = uniform64(reinterpret_cast<uint64_t>(reinterpret_cast<const char*>(g.A) + (size_t)(s0 + i * RA) * g.lda * ESZ));
         } else {
 #pragma unroll
             for (int i = 0; i < NA; ++i)
                 a_ptr[i] = uniform64(reinterpret_cast<uint64_t>(reinterpret_cast<const char*>(g.A) + (size_t)(t0 + i * RA) * g.lda * ESZ));
-            b_ptr[0] = uniform64(reinterpret_cast<uint64_t>(g.B));
+            b_ptr[0] = uniform64(reinterpret_cast<uint64_t>(reinterpret_cast<const char*>(g.B) + (size_t)s0 * ESZ));
         }
     };
     // FORM 1: the B stage (a KT x 16 T piece of the coefficient matrix) as a flat item list; threads beyond it are parked on
@@ -283,18 +294,17 @@ void gemm_strip_kernel(const StripArgs g) {
     // 16 x 16 block.
     constexpr unsigned kDropped = 0xFFFFFFFFu, kRange = 0x80000000u;
     unsigned voff_c[WN];           // FORM 0: per tile; FORM 1: fixed (column block 0; later blocks through the immediate offset)
-    unsigned voff_c_last = 0;      // FORM 1: the same for the last column block (columns >= n dropped)
-    uint64_t c_base = 0;           // FORM 0: first segment of the tile;  FORM 1: first row of the wave in the tile
-    if constexpr (FORM == 1) {
-        voff_c[0] = (unsigned)(((int64_t)(lane >> 4) * g.ldc + (lane & 15)) * ESZ);
-        voff_c_last = ((T - 1) * 16 + (lane & 15) < g.small) ? voff_c[0] : kDropped;
-    }
+    uint64_t c_base = 0;           // FORM 0: first segment and first row of the tile;  FORM 1: first row of the wave and first column of the tile
+    int c_s0 = 0;                  // the tile's start along the small extent
+    if constexpr (FORM == 1) voff_c[0] = (unsigned)(((int64_t)(lane >> 4) * g.ldc + (lane & 15)) * ESZ);
     auto aim_stores = [&](unsigned v) __attribute__((always_inline)) {
-        const int64_t t0 = tile_start(v);
+        int s0;
+        const int64_t t0 = tile_start(v, s0);
+        c_s0 = s0;
         if constexpr (FORM == 0) {
             const unsigned W = (unsigned)g.Wp;
             const unsigned seg0 = __builtin_amdgcn_readfirstlane((unsigned)t0 / W);
-            c_base = uniform64(reinterpret_cast<uint64_t>(reinterpret_cast<char*>(g.C) + (int64_t)seg0 * g.sc * ESZ));
+            c_base = uniform64(reinterpret_cast<uint64_t>(reinterpret_cast<char*>(g.C) + ((int64_t)seg0 * g.sc + (int64_t)s0 * g.ldc) * ESZ));
 #pragma unroll
             for (int o = 0; o < WN; ++o) {
                 const unsigned j = (unsigned)t0 + wave * 16 * WN + o * 16 + (lane & 15);
@@ -303,7 +313,7 @@ void gemm_strip_kernel(const StripArgs g) {
                 voff_c[o] = ok ? (unsigned)(((int64_t)(sj - seg0) * g.sc + (j - sj * W) + (int64_t)(lane >> 4) * g.ldc) * ESZ) : kDropped;
             }
         } else {
-            c_base = uniform64(reinterpret_cast<uint64_t>(reinterpret_cast<char*>(g.C) + (t0 + wave * 16 * WN) * g.ldc * ESZ));
+            c_base = uniform64(reinterpret_cast<uint64_t>(reinterpret_cast<char*>(g.C) + ((t0 + wave * 16 * WN) * g.ldc + s0) * ESZ));
         }
     };
     auto store_one = [&](int s, int o, int r, const auto& rsrc, unsigned off, int soff) __attribute__((always_inline)) {
@@ -326,7 +336,9 @@ void gemm_strip_kernel(const StripArgs g) {
 #pragma unroll
                 for (int o = 0; o < WN; ++o) {
                     unsigned off = voff_c[o];
-                    if (s == T - 1) off = (s * 16 + 4 * r + (lane >> 4) < g.small) ? off : kDropped;      // (last row block only)
+                    // (a block that reaches past the last row -- wave-uniform; with one tile along the small extent only the
+                    // last block can)
+                    if (c_s0 + s * 16 + 16 > g.small) off = (c_s0 + s * 16 + 4 * r + (lane >> 4) < g.small) ? off : kDropped;
                     store_one(s, o, r, rsrc, off, 0);
                 }
             }
@@ -342,7 +354,9 @@ void gemm_strip_kernel(const StripArgs g) {
                     // rows past the last one lie past the end of C: dropped by the range check
                     const auto rsrc = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void*>(base), (short)0,
                                                                         (int)bytes_left(g.c_end, base), 0x00020000);
-                    store_one(s, o, r, rsrc, s == T - 1 ? voff_c_last : voff_c[0], 0);
+                    unsigned off = voff_c[0];
+                    if (c_s0 + s * 16 + 16 > g.small) off = (c_s0 + s * 16 + (lane & 15) < g.small) ? off : kDropped;      // (columns >= n)
+                    store_one(s, o, r, rsrc, off, 0);
                 }
             }
         }
@@ -445,7 +459,7 @@ int launch_strip(StripArgs g, hipStream_t stream) {
     constexpr int NA = (A_ROWS + 63) / 64;
     constexpr int SB = FORM == 0 ? TILE + 16 : 16 * T + ((T & 1) ? 32 : 16);
     const size_t lds = sizeof(double) * 2 * NP * (size_t)(NA * 64 * (KT + 2) + KT * SB);
-    const int64_t tiles = cdiv(g.big, TILE);
+    const int64_t tiles = cdiv(g.big, TILE) * g.nsmall;
     if (tiles * g.nk >= (int64_t(1) << 31)) return 1;
     g.total = (unsigned)tiles;
     int64_t P = device_cu_count();
@@ -464,6 +478,7 @@ int launch_strip(StripArgs g, hipStream_t stream) {
 // the accumulators fit (fp64: T <= kWideMaxT) and the tile list is long enough to fill the chip
 constexpr int kWideMaxT = 10;
 constexpr int kMaxT = 16, kMaxTComplex = 8;
+constexpr int kMaxSmallTiles = 4;      // tiles along the small extent (fp64 up to 1024, complex128 up to 512 orbitals)
 
 template <int FORM>
 int launch_strip_t(bool cx, int t, bool wide, const StripArgs& g, hipStream_t stream) {
@@ -506,7 +521,8 @@ int gemm_strip_try(int dtype, const double* A, const double* B, double* C, int64
     if (m <= 0 || n <= 0 || k <= 0 || batch <= 0 || k >= (int64_t(1) << 30)) return 1;
     const bool cx = dtype == QS_C128;
     const int64_t esz = cx ? 16 : 8;
-    const int max_small = 16 * (cx ? kMaxTComplex : kMaxT);
+    const int max_t = cx ? kMaxTComplex : kMaxT;
+    const int max_small = 16 * max_t * kMaxSmallTiles;
     if (cx && (!aligned(A, 16) || !aligned(B, 16) || !aligned(C, 16))) return 1;
     // which extent is the small one: A shared by the batch and m small -> tall tiles over virtual columns; otherwise one
     // product with n small -> wide tiles over the rows
@@ -538,6 +554,9 @@ int gemm_strip_try(int dtype, const double* A, const double* B, double* C, int64
         g.big = m; g.W = g.Wp = 0; g.small = (int)n;
         t = (int)cdiv(n, 16);
     }
+    // an extent beyond one tile (16 blocks of fp64, 8 of complex128): the fewest tiles along it, equally high
+    g.nsmall = (int)cdiv(t, max_t);
+    t = (int)cdiv(t, g.nsmall);
     g.a_end = reinterpret_cast<uint64_t>(A) + (uint64_t)(((m - 1) * lda + k) * esz);
     g.b_end = reinterpret_cast<uint64_t>(B) + (uint64_t)(((batch - 1) * sb + (k - 1) * ldb + n) * esz);
     g.c_end = reinterpret_cast<uint64_t>(C) + (uint64_t)(((batch - 1) * sc + (m - 1) * ldc + n) * esz);
@@ -546,12 +565,13 @@ int gemm_strip_try(int dtype, const double* A, const double* B, double* C, int64
     static const int wide_env = [] { const char* e = getenv("QS_STRIP_WIDE"); return e ? atoi(e) : -1; }();      // (tuning runs)
     bool wide = !cx && t <= kWideMaxT && cdiv(g.big, 256) >= 4 * (int64_t)slots;
     if (wide_env >= 0) wide = !cx && wide_env != 0 && t <= kWideMaxT;
-    const int64_t tiles = cdiv(g.big, wide ? 256 : 128);
+    const int64_t tiles = cdiv(g.big, wide ? 256 : 128) * g.nsmall;
     if (g_tune.gemm_strip == 1) {
         // estimated time: rounds of the tile list over the CUs (one eight-wave workgroup each = both slots of the other
         // kernels' two four-wave workgroups) x tile area / relative rate
         const double rounds = tiles > 8 * slots ? tiles / slots : ceil(tiles / slots);
-        const double cost = rounds * (16.0 * t) * (wide ? 256.0 : 128.0) / 2.0 / strip_weight(cx, t, wide);
+        // (several tiles along the small extent read the streamed operand that often, the repeats from L2)
+        const double cost = rounds * (16.0 * t) * (wide ? 256.0 : 128.0) / 2.0 / (strip_weight(cx, t, wide) * (g.nsmall > 1 ? 0.97 : 1.0));
         if (!(cost < other_cost)) return 1;
     }
     return form == 0 ? launch_strip_t<0>(cx, t, wide, g, stream) : launch_strip_t<1>(cx, t, wide, g, stream);

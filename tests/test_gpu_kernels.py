@@ -616,6 +616,7 @@ def test_fitted_tile_shapes_vs_oracle(K, m, n, k, batch):
     (129, 129, 129, 17), (97, 97 * 5, 97, 7),       # odd sizes: 8-byte items
     (253, 600, 253, 2), (256, 384, 256, 2),         # sixteen row blocks (one register set)
     (20, 300, 20, 5), (1, 7, 1, 3), (17, 33, 5, 2),
+    (300, 700, 300, 2), (288, 288 * 3, 288, 1), (3000, 300, 300, 1), (700, 513, 40, 1), (520, 300, 77, 3),   # SEVERAL tiles along the small extent
     (70000, 130, 130, 1),      # contraction d: the rows of the tensor against the coefficient matrix (wide tiles)
     (4097, 100, 100, 1), (2000, 97, 97, 1), (1500, 253, 253, 1), (1000, 256, 256, 1), (300, 7, 3, 1), (129, 16, 4, 1),
 ])
@@ -647,6 +648,7 @@ def test_strip_kernels_vs_oracle_and_bit_identical_to_the_general_kernel(K, m, n
 
 @pytest.mark.parametrize("m,n,k,batch", [
     (66, 66, 66, 30), (80, 6400, 80, 3), (100, 100000, 100, 1), (127, 127, 127, 9), (128, 384, 128, 2), (112, 112 * 3, 112, 5),
+    (130, 130, 130, 9), (153, 306, 153, 3), (200, 400, 200, 1), (2000, 153, 153, 1), (1000, 250, 250, 1), (300, 260, 31, 2),   # several tiles along the small extent
     (20, 300, 20, 5), (1, 7, 1, 3), (17, 33, 5, 2),
     (30000, 66, 66, 1), (4097, 100, 100, 1), (2000, 97, 97, 1), (1500, 127, 127, 1), (1000, 128, 128, 1), (300, 7, 3, 1),
 ])
@@ -674,7 +676,7 @@ def test_complex_strip_kernels_vs_oracle_and_bit_identical_to_the_general_kernel
         K.tuning_reset()
 
 
-@pytest.mark.parametrize("L,M", [(66, 66), (72, 70), (80, 80), (100, 100), (91, 112), (127, 127)])
+@pytest.mark.parametrize("L,M", [(66, 66), (72, 70), (80, 80), (100, 100), (91, 112), (127, 127), (130, 130), (144, 150)])
 def test_complex_transform_on_the_strip_kernels_equals_the_general_kernel(K, L, M):
     g = torch.Generator(device="cuda:0").manual_seed(L + M)
     u = torch.complex(torch.rand(L, L, L, L, dtype=torch.float64, device="cuda:0", generator=g),
