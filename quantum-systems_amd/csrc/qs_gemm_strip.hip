@@ -521,7 +521,8 @@ int gemm_strip_try(int dtype, const double* A, const double* B, double* C, int64
     if (m <= 0 || n <= 0 || k <= 0 || batch <= 0 || k >= (int64_t(1) << 30)) return 1;
     const bool cx = dtype == QS_C128;
     const int64_t esz = cx ? 16 : 8;
-    const int max_t = cx ? kMaxTComplex : kMaxT;
+    static const int max_t_env = [] { const char* e = getenv("QS_STRIP_MAXT"); return e ? atoi(e) : 0; }();      // (tuning runs)
+    const int max_t = (max_t_env > 0 && !cx) ? max_t_env : (cx ? kMaxTComplex : kMaxT);
     const int max_small = 16 * max_t * kMaxSmallTiles;
     if (cx && (!aligned(A, 16) || !aligned(B, 16) || !aligned(C, 16))) return 1;
     // which extent is the small one: A shared by the batch and m small -> tall tiles over virtual columns; otherwise one
@@ -556,6 +557,10 @@ int gemm_strip_try(int dtype, const double* A, const double* B, double* C, int64
     }
     // an extent beyond one tile (16 blocks of fp64, 8 of complex128): the fewest tiles along it, equally high
     g.nsmall = (int)cdiv(t, max_t);
+    // fp64, an even number of 12 ... 16 blocks: two tiles of half the height -- they fit the 256-wide form (half the staging of
+    // the shared operand per product), the streamed operand is read twice, the repeat from L2: l = 190 +1.5 %, 224 +3 %, 253 +3 %
+    // (176 = 11 and 208 = 13 blocks would pad to 12 / 14: -5 % / -3.5 %; profiles/r04_strip_ablation.txt)
+    if (!cx && max_t_env <= 0 && g.nsmall == 1 && t >= 12 && t % 2 == 0) g.nsmall = 2;
     t = (int)cdiv(t, g.nsmall);
     g.a_end = reinterpret_cast<uint64_t>(A) + (uint64_t)(((m - 1) * lda + k) * esz);
     g.b_end = reinterpret_cast<uint64_t>(B) + (uint64_t)(((batch - 1) * sb + (k - 1) * ldb + n) * esz);
