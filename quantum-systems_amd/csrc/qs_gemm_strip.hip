@@ -80,7 +80,15 @@ void gemm_strip_kernel(const StripArgs g) {
     constexpr int NB = (B_ITEMS + NT - 1) / NT;               // item steps of the B stage
     constexpr int RPS = FORM == 0 ? NT / IPR_B : 0;           // FORM 0: B rows per item step, whole (half) rows per wave
     // row pitch of the B stage: 16 mod 32 doubles, so that the four k rows of a fragment read fall on different banks
-    constexpr int SB = FORM == 0 ? TILE + 16 : 16 * T + ((T & 1) ? 32 : 16);
+    // fp64, FORM 0, two column blocks per wave: lane c owns the ADJACENT columns 32 w + 2 c and 32 w + 2 c + 1 (the trick of
+    // qs_gemm_fast.hip): ONE 16-byte LDS read feeds both blocks and the result leaves in 16-byte stores -- half the store
+    // instructions (the stores are what these kernels wait on, profiles/r04_strip_ablation.txt).  Row pitch 0 mod 32 for those reads.
+#ifdef QS_STRIP_NO_PAIR      // (A/B builds)
+    constexpr bool kPair = false;
+#else
+    constexpr bool kPair = !CX && FORM == 0 && WN == 2;
+#endif
+    constexpr int SB = FORM == 0 ? (kPair ? TILE : TILE + 16) : 16 * T + ((T & 1) ? 32 : 16);
     constexpr int A_PLANE = NA * RA * SA, B_PLANE = KT * SB;
     constexpr int A_STAGE = NP * A_PLANE, B_STAGE = NP * B_PLANE;
     static_assert(FORM == 1 || (NT % IPR_B == 0 && KT % RPS == 0), "FORM 0: item steps cover whole B rows");
@@ -165,7 +173,7 @@ void gemm_strip_kernel(const StripArgs g) {
     double* st_a = As + (tid / IPR_A) * SA + (tid % IPR_A) * EPI;
     const double* rd_a = FORM == 0 ? As + (lane & 15) * SA + (lane >> 4)
                                    : As + (wave * 16 * WN + (lane & 15)) * SA + (lane >> 4);
-    const double* rd_b = FORM == 0 ? Bs + (lane >> 4) * SB + wave * 16 * WN + (lane & 15)
+    const double* rd_b = FORM == 0 ? Bs + (lane >> 4) * SB + wave * 16 * WN + (kPair ? 2 : 1) * (lane & 15)
                                    : Bs + (lane >> 4) * SB + (lane & 15);
 
     item_t ra[SETS][NA], rb[SETS][NB];
@@ -255,8 +263,14 @@ void gemm_strip_kernel(const StripArgs g) {
             if constexpr (FORM == 0) {
 #pragma unroll
                 for (int i = 0; i < T; ++i) sf[p][i] = as[p * A_PLANE + i * 16 * SA + kk * 4];
+                if constexpr (kPair) {
+                    const f64x2 v = *reinterpret_cast<const f64x2*>(bs + kk * 4 * SB);
+                    of[0][0] = v[0];
+                    of[0][1] = v[1];
+                } else {
 #pragma unroll
-                for (int o = 0; o < WN; ++o) of[p][o] = bs[p * B_PLANE + kk * 4 * SB + o * 16];
+                    for (int o = 0; o < WN; ++o) of[p][o] = bs[p * B_PLANE + kk * 4 * SB + o * 16];
+                }
             } else {
 #pragma unroll
                 for (int o = 0; o < WN; ++o) of[p][o] = as[p * A_PLANE + o * 16 * SA + kk * 4];
@@ -305,12 +319,24 @@ void gemm_strip_kernel(const StripArgs g) {
             const unsigned W = (unsigned)g.Wp;
             const unsigned seg0 = __builtin_amdgcn_readfirstlane((unsigned)t0 / W);
             c_base = uniform64(reinterpret_cast<uint64_t>(reinterpret_cast<char*>(g.C) + ((int64_t)seg0 * g.sc + (int64_t)s0 * g.ldc) * ESZ));
-#pragma unroll
-            for (int o = 0; o < WN; ++o) {
-                const unsigned j = (unsigned)t0 + wave * 16 * WN + o * 16 + (lane & 15);
+            if constexpr (kPair) {
+                // the lane's column pair (j even, never across a segment boundary: Wp is even): voff_c[0] for the 16-byte store of
+                // both, voff_c[1] for the 8-byte store of the first one alone (the last column of an odd segment)
+                const unsigned j = (unsigned)t0 + wave * 32 + 2 * (lane & 15);
                 const unsigned sj = j / W;
-                const bool ok = j < (unsigned)g.big && j - sj * W < (unsigned)g.W;
-                voff_c[o] = ok ? (unsigned)(((int64_t)(sj - seg0) * g.sc + (j - sj * W) + (int64_t)(lane >> 4) * g.ldc) * ESZ) : kDropped;
+                const unsigned rc = j - sj * W;
+                const unsigned off = (unsigned)(((int64_t)(sj - seg0) * g.sc + rc + (int64_t)(lane >> 4) * g.ldc) * ESZ);
+                const bool in = j < (unsigned)g.big;
+                voff_c[0] = (in && rc + 1 < (unsigned)g.W) ? off : kDropped;
+                voff_c[1] = (in && rc + 1 == (unsigned)g.W) ? off : kDropped;
+            } else {
+#pragma unroll
+                for (int o = 0; o < WN; ++o) {
+                    const unsigned j = (unsigned)t0 + wave * 16 * WN + o * 16 + (lane & 15);
+                    const unsigned sj = j / W;
+                    const bool ok = j < (unsigned)g.big && j - sj * W < (unsigned)g.W;
+                    voff_c[o] = ok ? (unsigned)(((int64_t)(sj - seg0) * g.sc + (j - sj * W) + (int64_t)(lane >> 4) * g.ldc) * ESZ) : kDropped;
+                }
             }
         } else {
             c_base = uniform64(reinterpret_cast<uint64_t>(reinterpret_cast<char*>(g.C) + ((t0 + wave * 16 * WN) * g.ldc + s0) * ESZ));
@@ -333,13 +359,28 @@ void gemm_strip_kernel(const StripArgs g) {
             for (int r = 0; r < 4; ++r) {
                 const uint64_t base = uniform64(c_base) + (uint64_t)(s * 16 + 4 * r) * ldc_b;
                 const auto rsrc = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void*>(base), (short)0, (int)kRange, 0x00020000);
+                // (a block that reaches past the last row -- wave-uniform; with one tile along the small extent only the last
+                // block can)
+                const bool partial = c_s0 + s * 16 + 16 > g.small;
+                const bool row_ok = c_s0 + s * 16 + 4 * r + (lane >> 4) < g.small;
+                if constexpr (kPair) {
+                    const double v0 = acc[0][s][0][r], v1 = acc[0][s][1][r];
+                    const f64x2 v = {v0, v1};
+                    unsigned off = voff_c[0];
+                    if (partial) off = row_ok ? off : kDropped;
+                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, v), rsrc, (int)off, 0, 2);
+                    if (g.W & 1) {      // (wave-uniform: odd segments end in a single column)
+                        unsigned off1 = voff_c[1];
+                        if (partial) off1 = row_ok ? off1 : kDropped;
+                        __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2_t, v0), rsrc, (int)off1, 0, 2);
+                    }
+                } else {
 #pragma unroll
-                for (int o = 0; o < WN; ++o) {
-                    unsigned off = voff_c[o];
-                    // (a block that reaches past the last row -- wave-uniform; with one tile along the small extent only the
-                    // last block can)
-                    if (c_s0 + s * 16 + 16 > g.small) off = (c_s0 + s * 16 + 4 * r + (lane >> 4) < g.small) ? off : kDropped;
-                    store_one(s, o, r, rsrc, off, 0);
+                    for (int o = 0; o < WN; ++o) {
+                        unsigned off = voff_c[o];
+                        if (partial) off = row_ok ? off : kDropped;
+                        store_one(s, o, r, rsrc, off, 0);
+                    }
                 }
             }
         } else {
@@ -457,7 +498,12 @@ int launch_strip(StripArgs g, hipStream_t stream) {
     constexpr int TILE = 128 * WN;
     constexpr int A_ROWS = FORM == 0 ? 16 * T : TILE;
     constexpr int NA = (A_ROWS + 63) / 64;
-    constexpr int SB = FORM == 0 ? TILE + 16 : 16 * T + ((T & 1) ? 32 : 16);
+#ifdef QS_STRIP_NO_PAIR
+    constexpr bool kPair = false;
+#else
+    constexpr bool kPair = !CX && FORM == 0 && WN == 2;
+#endif
+    constexpr int SB = FORM == 0 ? (kPair ? TILE : TILE + 16) : 16 * T + ((T & 1) ? 32 : 16);
     const size_t lds = sizeof(double) * 2 * NP * (size_t)(NA * 64 * (KT + 2) + KT * SB);
     const int64_t tiles = cdiv(g.big, TILE) * g.nsmall;
     if (tiles * g.nk >= (int64_t(1) << 31)) return 1;
