@@ -84,7 +84,7 @@ int resident_workgroups(const void* kern, PerDeviceInt& cache, int fallback) {
 
 thread_local Tuning g_tune;
 
-static thread_local char g_dispatch[1024] = "";
+static thread_local char g_dispatch[4096] = "";
 static thread_local size_t g_dispatch_len = 0;
 
 void dispatch_reset() {

@@ -533,6 +533,7 @@ int launch_strip_t(bool cx, int t, bool wide, const StripArgs& g, hipStream_t st
 #ifdef QS_DEV_FEW_SHAPES      // development / sanitizer builds of the HOST side
             case 5: return launch_strip<true, FORM, 5, 1>(g, stream);
 #else
+            // (256-wide complex tiles measured and dropped: T = 5 spills, 31.9 against 39.7 TFLOP/s at l = 66; T = 4 level)
 #define QS_STRIP(TT) case TT: return launch_strip<true, FORM, TT, 1>(g, stream);
             QS_STRIP(1) QS_STRIP(2) QS_STRIP(3) QS_STRIP(4) QS_STRIP(5) QS_STRIP(6) QS_STRIP(7) QS_STRIP(8)
 #undef QS_STRIP
@@ -617,6 +618,7 @@ int gemm_strip_try(int dtype, const double* A, const double* B, double* C, int64
     bool wide = !cx && t <= kWideMaxT && cdiv(g.big, 256) >= 4 * (int64_t)slots;
     if (wide_env >= 0) wide = !cx && wide_env != 0 && t <= kWideMaxT;
     const int64_t tiles = cdiv(g.big, wide ? 256 : 128) * g.nsmall;
+    if (g_tune.gemm_strip == 1 && t * g.nsmall < 3) return 1;      // (up to 32 rows / columns: the other kernels' ground, not measured here)
     if (g_tune.gemm_strip == 1) {
         // estimated time: rounds of the tile list over the CUs (one eight-wave workgroup each = both slots of the other
         // kernels' two four-wave workgroups) x tile area / relative rate
