@@ -448,7 +448,16 @@ const char* qs_last_dispatch(void);
  *     streamed complex128 / real-tensor-complex-coefficients kernel of 5-64
  *     orbitals: 0 never, 1 automatic, 2 wherever it exists), "gemm_fit"
  *     (fitted tile shapes of the general kernel: 0 never, 1 automatic, 2 always),
- *     "gemm_pick" (0 = tile shape by padded area only).
+ *     "gemm_pick" (0 = tile shape by padded area only), "gemm_strip" (the strip
+ *     kernels, which cover the small extent of a product with one tile to the
+ *     next multiple of 16: 0 never, 1 by estimated time, 2 wherever they
+ *     exist), "gemm_strip_w" (tuning runs: their relative rate in percent,
+ *     0 = built-in weights), "gemm_fast_unaligned" (0 = 8-byte global items at
+ *     odd strides as in rounds 1-3, 1 = 16-byte items at any 8-byte-aligned
+ *     address), "comm_drop_wait" (TEST HOOK of the sharded entry points: a bit
+ *     mask of stream waits between the caller's stream and the communicator's
+ *     to leave out -- the negative control of the asynchronous stand-in
+ *     transport, tests/test_gpu_async_transport.py; never set it elsewhere).
  *   qs_probe_mfma_f64: register-resident fp64 MFMA loop, `blocks` workgroups
  *     of 4 waves, each wave issuing iters*8 v_mfma_f64_16x16x4_f64
  *     (flops = blocks*4*iters*8*2048); `sink` is a device scratch of
