@@ -19,6 +19,11 @@
 #include <type_traits>
 
 #include "qs_common.h"
+
+// cache policy of the stores of the result (development: -DQS_S4B_STORE_AUX=n; 0 = default, 2 = non-temporal, 1 / 16 / 17 = sc0 / sc1 / both)
+#ifndef QS_S4B_STORE_AUX
+#define QS_S4B_STORE_AUX 0
+#endif
 #include "qs_sandwich4.h"
 
 // development: -DQS_S4B_EXPERIMENT=1 nobody runs the shared group's chains (every step branches around them),
@@ -278,7 +283,7 @@ __global__ __launch_bounds__(256, 1) void sandwich4b_kernel(const S4Args g) {
                 for (int rv = 0; rv < 3; ++rv) vox[par][rv] = (par == mpar && col_ok) ? v_out[rv] : kParkedB;
         }
         auto store_frag = [&](unsigned vofs, unsigned s_off, double val) __attribute__((always_inline)) {
-            __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2b, val), rs_out, (int)vofs, (int)s_off, 0);
+            __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2b, val), rs_out, (int)vofs, (int)s_off, QS_S4B_STORE_AUX);
         };
 
         // ---- phase 1
@@ -564,9 +569,9 @@ __global__ __launch_bounds__(256, 1) void sandwich4b_kernel(const S4Args g) {
                     });
                     const unsigned s_col = (unsigned)jg * jg_step;
                     __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2b, o0), rs_o,
-                        (int)(col_ok ? v_o[pg == N4 - 2 ? 1 : 0] : kParkedB), (int)(pg * pg_step + s_col), 0);
+                        (int)(col_ok ? v_o[pg == N4 - 2 ? 1 : 0] : kParkedB), (int)(pg * pg_step + s_col), QS_S4B_STORE_AUX);
                     __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2b, o1), rs_o,
-                        (int)(col_ok ? v_o[pg + 1 == N4 - 1 ? 2 : 0] : kParkedB), (int)((pg + 1) * pg_step + s_col), 0);
+                        (int)(col_ok ? v_o[pg + 1 == N4 - 1 ? 2 : 0] : kParkedB), (int)((pg + 1) * pg_step + s_col), QS_S4B_STORE_AUX);
                 });
             }
         }
