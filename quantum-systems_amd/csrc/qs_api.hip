@@ -280,6 +280,8 @@ namespace qs {
 // 91 1406 -> 1113); 96 itself level (0.98x): the tiled kernels keep it.
 static bool quad4s_wins(int64_t L, int64_t M) {
     if (L >= 9 && M >= 9 && L <= 32 && M <= 32) return true;
+    // (round 4: a basis of exactly 80 = 5 x 16 orbitals is the strip kernels' -- 597 against 678 us, found by tools/dispatch_guard.py)
+    if (L == 80 && M == 80) return false;
     return L >= 65 && M >= 65 && L <= 96 && M <= 96 && !(L == 96 && M == 96);
 }
 

@@ -33,6 +33,17 @@
 #include "qs_common.h"
 #include "qs_fast_items.h"
 
+// Cache policy of the stores of the result: 0 = default (write-back through L2), 2 = non-temporal.  Non-temporal stores looked
+// right (the output is read again only by the next contraction, after the whole tensor has passed through the caches) and are
+// level at sizes whose rows are whole 128-byte lines -- but at every other size a row piece ends in PARTIAL lines, which L2
+// merges under the default policy and the non-temporal path writes through one by one: default against non-temporal, same box:
+// l = 97 37.6 -> 40.0, 100 41.9 -> 43.5, 130 45.8 -> 47.8 TFLOP/s (112, 144, 160: level; profiles/r04_strip_ablation.txt).
+// (In the fused small-basis kernels, whose second pass reads the first one's result straight back, non-temporal stores cost
+// a factor 1.75: l = 55 105 -> 184 us.)
+#ifndef QS_STRIP_STORE_AUX
+#define QS_STRIP_STORE_AUX 0
+#endif
+
 namespace qs {
 
 typedef unsigned u32x2_t __attribute__((ext_vector_type(2)));
@@ -65,7 +76,10 @@ template <bool CX, int FORM, int T, int WN, int SETS>
 __global__ __launch_bounds__(512, 1)
 void gemm_strip_kernel(const StripArgs g) {
     constexpr int NP = CX ? 2 : 1;                            // LDS planes
-    constexpr int KT = CX ? 8 : 16, KS = KT / 4, NT = 512, SA = KT + 2;
+    // A rows: fp64 pads a row to KT + 2 (stride 18: conflict-free fragment reads).  complex128: no padding, the k index of a row
+    // XOR-ed with 2 ((row >> 2) & 3) instead, as in qs_gemm_fast.hip (the padded rows of stride 10 collided on every write of the
+    // A stage: SQ_LDS_BANK_CONFLICT 45 % of the LDS cycles of the tall form at l = 100, profiles/r04_final_pmc_l100_c128.txt)
+    constexpr int KT = CX ? 8 : 16, KS = KT / 4, NT = 512, SA = CX ? KT : KT + 2;
     constexpr int EPI = CX ? 1 : 2;                           // elements per 16-byte global item
     constexpr unsigned ESZ = CX ? 16 : 8;                     // bytes per element
     constexpr unsigned IB = 16;                               // bytes per global item
@@ -170,9 +184,13 @@ void gemm_strip_kernel(const StripArgs g) {
     const size_t a_step = KT * ESZ;
     const size_t b_step = (size_t)KT * g.ldb * ESZ;
 
-    double* st_a = As + (tid / IPR_A) * SA + (tid % IPR_A) * EPI;
+    double* st_a = CX ? As + (tid / IPR_A) * SA + ((tid % IPR_A) ^ (2 * (((tid / IPR_A) >> 2) & 3)))
+                      : As + (tid / IPR_A) * SA + (tid % IPR_A) * EPI;
     const double* rd_a = FORM == 0 ? As + (lane & 15) * SA + (lane >> 4)
                                    : As + (wave * 16 * WN + (lane & 15)) * SA + (lane >> 4);
+    // complex: the swizzled position of k = 4 kk + (lane >> 4) depends on kk -- one base per k-step of a stage (KS = 2)
+    const int swz_r = CX ? 2 * (((lane & 15) >> 2) & 3) : 0;
+    const double* rd_a_cx[2] = {rd_a - (lane >> 4) + ((lane >> 4) ^ swz_r), rd_a - (lane >> 4) + ((4 + (lane >> 4)) ^ swz_r) - 4};
     const double* rd_b = FORM == 0 ? Bs + (lane >> 4) * SB + wave * 16 * WN + (kPair ? 2 : 1) * (lane & 15)
                                    : Bs + (lane >> 4) * SB + (lane & 15);
 
@@ -256,7 +274,7 @@ void gemm_strip_kernel(const StripArgs g) {
     // fragments of k-step kk: the T shared ones (`sf`) and the wave's own (`of`)
     auto read_frags = [&](auto buf_c, int kk, double (&sf)[NP][T], double (&of)[NP][WN]) __attribute__((always_inline)) {
         constexpr int buf = decltype(buf_c)::value;
-        const double* as = rd_a + buf * A_STAGE;
+        const double* as = (CX ? rd_a_cx[kk & 1] : rd_a) + buf * A_STAGE;      // (rd_a_cx[1] is pre-biased by -4: the index below adds 4 kk)
         const double* bs = rd_b + buf * B_STAGE;
 #pragma unroll
         for (int p = 0; p < NP; ++p) {
@@ -347,9 +365,9 @@ void gemm_strip_kernel(const StripArgs g) {
         if constexpr (CX) {
             const double im = acc[1][s][o][r];
             const f64x2 v = {re, im};
-            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, v), rsrc, (int)off, soff, 2);
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, v), rsrc, (int)off, soff, QS_STRIP_STORE_AUX);
         } else {
-            __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2_t, re), rsrc, (int)off, soff, 2);
+            __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2_t, re), rsrc, (int)off, soff, QS_STRIP_STORE_AUX);
         }
     };
     auto store_block = [&](int s, uint64_t ldc_b) __attribute__((always_inline)) {
@@ -368,11 +386,11 @@ void gemm_strip_kernel(const StripArgs g) {
                     const f64x2 v = {v0, v1};
                     unsigned off = voff_c[0];
                     if (partial) off = row_ok ? off : kDropped;
-                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, v), rsrc, (int)off, 0, 2);
+                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, v), rsrc, (int)off, 0, QS_STRIP_STORE_AUX);
                     if (g.W & 1) {      // (wave-uniform: odd segments end in a single column)
                         unsigned off1 = voff_c[1];
                         if (partial) off1 = row_ok ? off1 : kDropped;
-                        __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2_t, v0), rsrc, (int)off1, 0, 2);
+                        __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2_t, v0), rsrc, (int)off1, 0, QS_STRIP_STORE_AUX);
                     }
                 } else {
 #pragma unroll
@@ -504,7 +522,7 @@ int launch_strip(StripArgs g, hipStream_t stream) {
     constexpr bool kPair = !CX && FORM == 0 && WN == 2;
 #endif
     constexpr int SB = FORM == 0 ? (kPair ? TILE : TILE + 16) : 16 * T + ((T & 1) ? 32 : 16);
-    const size_t lds = sizeof(double) * 2 * NP * (size_t)(NA * 64 * (KT + 2) + KT * SB);
+    const size_t lds = sizeof(double) * 2 * NP * (size_t)(NA * 64 * (CX ? KT : KT + 2) + KT * SB);
     const int64_t tiles = cdiv(g.big, TILE) * g.nsmall;
     if (tiles * g.nk >= (int64_t(1) << 31)) return 1;
     g.total = (unsigned)tiles;
