@@ -98,6 +98,10 @@ def test_a_missing_stream_wait_is_caught(built, drop, what, entry, weather, coal
     # the control: the same run with every wait in place is right ...
     rc, text = run_demo(built, world, L, M, mode, chunk, coalesce, 0, stall, entry, delay)
     assert rc == 0 and "ALL_RANKS_OK" in text, text
-    # ... and wrong without this one
-    rc, text = run_demo(built, world, L, M, mode, chunk, coalesce, drop, stall, entry, delay)
+    # ... and wrong without this one.  (A race is exposed by timing: the delay / the stall make it all but certain, every run so far
+    # showed it at the first attempt; up to three attempts keep a slow box from turning the control into a flaky test.)
+    for attempt in range(3):
+        rc, text = run_demo(built, world, L, M, mode, chunk, coalesce, drop, stall * (attempt + 1), entry, delay * (attempt + 1))
+        if rc == 1:
+            break
     assert rc == 1 and "SOME_RANK_WRONG" in text and "RANK_WRONG" in text, f"{what}: NOT caught\n{text}"
