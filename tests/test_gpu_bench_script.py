@@ -168,12 +168,12 @@ def test_a_hanging_leg_costs_only_itself_and_the_run_stays_inside_its_budget():
     for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT"):
         env.pop(k, None)
     cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--orbitals", "48",
-           "--no-cpu-baseline", "--no-probes", "--legs", "replicated,rows_rccl,rows", "--leg-timeout", "20", "--total-budget", "150"]
+           "--no-cpu-baseline", "--no-probes", "--legs", "replicated,rows_rccl,rows", "--leg-timeout", "20", "--total-budget", "300"]
     t0 = time.monotonic()
-    res = subprocess.run(cmd, capture_output=True, text=True, timeout=400, cwd=ROOT, env=env)
+    res = subprocess.run(cmd, capture_output=True, text=True, timeout=500, cwd=ROOT, env=env)
     wall = time.monotonic() - t0
     assert res.returncode == 0, res.stderr[-3000:]
-    assert wall < 150, wall
+    assert wall < 300, wall                       # (inside --total-budget; a warm box takes ~45 s)
     lines = [json.loads(ln) for ln in res.stdout.splitlines() if ln.strip().startswith("{")]
     assert len(lines) == 3 and lines[0]["provisional"] is True and list(lines[0]["legs"]) == ["replicated"]
     assert lines[0]["value"] > 0 and lines[0]["parity"]["ok"] is True          # what stands if everything after it is lost
