@@ -506,7 +506,34 @@ def case_fock_energy():
     save("fock_energy_random_basis", **out)
 
 
+def case_mid_size_sampled():
+    """Sizes that run through the streamed and strip kernels (78 ... 180 orbitals): the tensors are too large to commit, so the
+    inputs come from a closed integer formula (tests/_lattice_inputs.py) and the fixture holds sampled outputs of the
+    reference's transform plus two whole-tensor sums."""
+    sys.path.insert(0, os.path.dirname(HERE))
+    import _lattice_inputs as li
+
+    arrays = {}
+    for name, L, M, ucplx, ccplx, salt in li.CASES:
+        u = li.tensor_np(L, salt, ucplx)
+        C, Ct = li.case_inputs_np(L, M, ucplx, ccplx, salt)
+        out = BasisSet.transform_two_body_elements(u, C, np, C_tilde=Ct)
+        del u
+        pos = li.sample_positions(M, li.N_SAMPLES, salt)
+        arrays[name + "_pos"] = pos
+        arrays[name + "_val"] = out[pos[:, 0], pos[:, 1], pos[:, 2], pos[:, 3]]
+        arrays[name + "_sum"] = np.array(out.sum())
+        arrays[name + "_abs_sum"] = np.array(np.abs(out).sum())
+        arrays[name + "_max_abs"] = np.array(np.abs(out).max())
+        print(name, out.shape, out.dtype, float(arrays[name + "_max_abs"]))
+        del out
+    save("mid_size_sampled", **arrays)
+
+
 if __name__ == "__main__":
+    if len(sys.argv) > 1 and sys.argv[1] == "midsize":
+        case_mid_size_sampled()
+        sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "sincspin":
         case_sinc_dvr_spin()
         sys.exit(0)
@@ -533,3 +560,4 @@ if __name__ == "__main__":
     case_tdho_one_body()
     case_fock_energy()
     case_sinc_dvr_spin()
+    case_mid_size_sampled()

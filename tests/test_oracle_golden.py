@@ -281,3 +281,40 @@ def test_fock_and_energy_match_reference_classes(golden):
     np.testing.assert_allclose(
         orc.reference_energy(sb["h"], sb["u"], nb, sb["nuclear_repulsion_energy"]), g["b_cb_energy"], **TIGHT)
     np.testing.assert_allclose(orc.fock_matrix(sb["h"], sb["u"], nb), g["b_cb_fock"], **TIGHT)
+
+
+# ------------------------------------------------------------------ sizes beyond the committed tensors
+
+
+def test_formula_inputs_are_the_same_from_numpy_and_torch():
+    import torch
+
+    import _lattice_inputs as li
+
+    for cplx in (False, True):
+        a = li.tensor_np(11, 5, cplx)
+        b = li.tensor_torch(11, 5, cplx).numpy()
+        assert a.dtype == b.dtype and np.array_equal(a, b)
+        k = a.real * 32768                                  # every value is an integer / 32768: nothing to round anywhere
+        assert np.array_equal(k, np.round(k)) and np.abs(k).max() <= 32768
+    assert len({tuple(p) for p in li.sample_positions(100, li.N_SAMPLES, 2)}) > li.N_SAMPLES - 8
+
+
+@pytest.mark.parametrize("name", ["f64_78", "f64_100", "c128_72"])
+def test_oracle_matches_reference_samples_at_mid_size(golden, name):
+    # tests/golden/mid_size_sampled.npz: the REFERENCE's transform of formula inputs at 78 ... 180 orbitals, sampled; the
+    # oracle is checked on the cases that take it seconds (the GPU tests check the HIP path on all of them)
+    import _lattice_inputs as li
+
+    g = golden("mid_size_sampled")
+    _, L, M, ucplx, ccplx, salt = next(c for c in li.CASES if c[0] == name)
+    C, Ct = li.case_inputs_np(L, M, ucplx, ccplx, salt)
+    out = orc.transform_two_body(li.tensor_np(L, salt, ucplx), C, Ct)
+    pos = g[name + "_pos"]
+    assert np.array_equal(pos, li.sample_positions(M, li.N_SAMPLES, salt))
+    got = out[pos[:, 0], pos[:, 1], pos[:, 2], pos[:, 3]]
+    scale = float(g[name + "_max_abs"])
+    assert got.dtype == g[name + "_val"].dtype
+    assert np.abs(got - g[name + "_val"]).max() <= 1e-12 * scale
+    assert abs(out.sum() - g[name + "_sum"]) <= 1e-12 * float(g[name + "_abs_sum"])
+    assert abs(np.abs(out).sum() - g[name + "_abs_sum"]) <= 1e-12 * float(g[name + "_abs_sum"])
