@@ -18,9 +18,9 @@ import torch
 from quantum_systems_amd import kernels as K
 
 ALTERNATIVES = [      # name, tuning keys, sizes it can change anything for
-    ("strip_off", {"gemm_strip": 0}, lambda l, cx: l > 32 and (not cx or l <= 128)),
+    ("strip_off", {"gemm_strip": 0}, lambda l, cx: l > 32),
     ("strip_forced", {"gemm_strip": 2, "quad4s": 0, "pair4c": 0, "sandwich": 0, "slab_pair": 0, "gemm_stream": 0},
-     lambda l, cx: l > 32 and (not cx or l <= 128)),
+     lambda l, cx: l > 32),
     ("streamed_off", {"quad4s": 0, "pair4c": 0}, lambda l, cx: l <= 96),
     ("streamed_forced", {"quad4s": 2, "pair4c": 2}, lambda l, cx: 5 <= l <= (64 if cx else 96)),
     ("fused_off", {"sandwich": 0, "small4": 0, "quad4s": 0, "pair4c": 0, "slab_pair": 0}, lambda l, cx: l <= 96),
@@ -59,7 +59,7 @@ def main():
     for cx in dtypes:
         curve = []
         for l in sizes:
-            if cx and l > 224:
+            if cx and l > 260:
                 continue
             a = torch.randn((l,) * 4, dtype=torch.float64, device=dev, generator=g)
             u = torch.complex(a, torch.randn((l,) * 4, dtype=torch.float64, device=dev, generator=g)) if cx else a
