@@ -834,9 +834,16 @@ class ChangeBasisPlan:
         if (C_tilde is not None) != self.explicit_bra:
             raise ValueError("this plan was captured " + ("with" if self.explicit_bra else "without") + " explicit bra coefficients")
         with torch._C.DisableTorchFunctionSubclass():
-            self.C.copy_(C)                               # (shape and dtype checked by copy_)
-            if self.explicit_bra:
-                self.Ct.copy_(C_tilde)
+            # (copy_ would broadcast a vector and drop an imaginary part without a word: checked here)
+            for name, src, dst in (("C", C, self.C), ("C_tilde", C_tilde, self.Ct)):
+                if src is None:
+                    continue
+                src = torch.as_tensor(src)
+                if tuple(src.shape) != (self.l, self.l):
+                    raise ValueError(f"ChangeBasisPlan: {name} must be ({self.l}, {self.l}), got {tuple(src.shape)}")
+                if src.is_complex() and not self.dtype.is_complex:
+                    raise TypeError(f"ChangeBasisPlan: complex {name} for a plan captured on real arrays (promote the basis set before planning)")
+                dst.copy_(src)
             self._graphs[self._cur].replay()
         self._cur ^= 1
         self._bind(self._cur)

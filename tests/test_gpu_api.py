@@ -536,5 +536,30 @@ def test_change_basis_plan_replays_change_basis_bit_for_bit(l, spin):
         plan2(Cs[3])
     # what a plan does not do
     rect = torch.from_numpy(rng.standard_normal((n, n - 1))).cuda()
-    with pytest.raises(RuntimeError):
+    with pytest.raises(ValueError):
         plan(rect.to(torch.complex128))
+    with pytest.raises(ValueError):
+        plan(Cs[0][0])                                  # a vector would broadcast under copy_: refused
+
+
+def test_change_basis_plan_on_real_arrays_refuses_complex_coefficients():
+    # the dtype of a plan's arrays is fixed when it is captured: a complex C for real arrays is an error, not a silent cast;
+    # a real C replays change_basis bit for bit, numpy coefficients are taken as they are
+    l = 10
+    rng = np.random.default_rng(21)
+    h, u = rng.standard_normal((l, l)), rng.standard_normal((l,) * 4)
+
+    def system():
+        bs = qsa.BasisSet(l, 1, np=hip)
+        bs.h, bs.s, bs.u = hip.asarray(h), hip.asarray(np.eye(l)), hip.asarray(u)
+        return bs
+
+    a, b = system(), system()
+    plan = b.change_basis_plan()
+    C = np.linalg.qr(rng.standard_normal((l, l)))[0]
+    a.change_basis(hip.asarray(C))
+    plan(C)
+    assert torch.equal(torch.as_tensor(a.u), torch.as_tensor(b.u)) and torch.equal(torch.as_tensor(a.h), torch.as_tensor(b.h))
+    with pytest.raises(TypeError):
+        plan(C + 0.5j)
+    assert torch.equal(torch.as_tensor(a.u), torch.as_tensor(b.u))      # the refused call changed nothing
