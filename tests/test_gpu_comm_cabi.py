@@ -64,3 +64,27 @@ def test_comm_argument_errors(comm):
     assert rc == -4                                                                 # QS_ERR_WORKSPACE
     with pytest.raises(ValueError):
         K.RcclComm(0, 1, b"short")
+
+
+def test_one_rank_of_many_with_absent_peers_tool():
+    # tools/config4_one_rank.py: one rank's share of a sharded transform as rank r of G through the C entry, the peers replaced by
+    # a stand-in that drops sends and delivers zeros (tests/cabi/absent_peers_rccl.cpp) -- the tool that ran configs[4]'s rank at
+    # its size (profiles/r04_config4_one_rank_of_8_at_size.txt).  Here small: the result must be the transform of the tensor whose
+    # only non-zero rows are the rank's (the tool's own check), both dtypes, uneven split.
+    import json
+    import os
+    import shutil
+    import subprocess
+    import sys
+
+    if not (shutil.which("hipcc") or os.path.exists("/opt/rocm/bin/hipcc")):
+        pytest.skip("no hipcc on this box")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for args in (["--orbitals", "26", "--world", "4", "--rank", "2"], ["--orbitals", "21", "--world", "8", "--rank", "7", "--dtype", "f64"]):
+        env = {k: v for k, v in os.environ.items() if k != "QS_AMD_RCCL_LIB"}
+        res = subprocess.run([sys.executable, os.path.join(root, "tools", "config4_one_rank.py"), "--steps", "1"] + args,
+                             capture_output=True, text=True, timeout=600, env=env, cwd=root)
+        assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-2000:]
+        line = json.loads([ln for ln in res.stdout.splitlines() if ln.startswith("{")][-1])
+        assert line["parity_ok"] and line["max_rel_err_sampled_planes"] <= 1e-12
+        assert line["exchange_gb_per_step"]["sent"] >= 0 and line["rows_in"] >= 1
