@@ -4,7 +4,8 @@ one-GPU box: 64 rows of 2 GiB in, 64 rows out, the C-ABI call `qs_transform_two_
 The seven peers do not exist: librccl is replaced by tests/cabi/absent_peers_rccl.cpp (sends dropped, receives deliver zeros --
 what the exchange would deliver if every other rank held rows of zeros).  What this measures: that the rank's buffers fit the
 GPU (266-270 GiB of 288), the rank's products at their real extents, its share of the exchange as bytes.
-What it cannot measure: the links.  The result is checked: it must be the transform of the tensor whose only non-zero
+What it cannot measure: the links -- `--link-gbs x` models their TIME (every exchange step holds the communicator's stream for
+the bytes of one peer / x GB/s; seven separate full-duplex links), which shows how much of it the stream pipeline hides.  The result is checked: it must be the transform of the tensor whose only non-zero
 leading rows are this rank's -- sampled (q', r') planes against a dense contraction in torch.
 
     python tools/config4_one_rank.py [--orbitals 512] [--world 8] [--rank 0] [--steps 2] [--dtype c128|f64]
@@ -40,10 +41,15 @@ def main():
     ap.add_argument("--dtype", default="c128")
     ap.add_argument("--chunk-rows", type=int, default=0)
     ap.add_argument("--samples", type=int, default=3)
+    ap.add_argument("--coalesce", action="store_true", help="the exchange with one message per peer and step (qs_comm_set_option rows_coalesce)")
+    ap.add_argument("--link-gbs", type=float, default=0.0,
+                    help="model the link TIME: every exchange step holds the communicator's stream for (bytes of one peer) / this many GB/s")
     a = ap.parse_args()
     tmp = tempfile.mkdtemp(prefix="absent_peers_")
     so = build_transport(tmp)
     os.environ["QS_AMD_RCCL_LIB"] = so
+    if a.link_gbs > 0:
+        os.environ["ABSENT_PEERS_LINK_GBS"] = str(a.link_gbs)
 
     import torch
 
@@ -71,7 +77,7 @@ def main():
     C = torch.linalg.qr(C)[0].contiguous()
     Ct = C.conj().T.contiguous()
     torch.cuda.empty_cache()
-    comm = K.RcclComm(r, G, K.RcclComm.unique_id())
+    comm = K.RcclComm(r, G, K.RcclComm.unique_id(), rows_coalesce=a.coalesce)
     lib = ctypes.CDLL(so)
     lib.absent_peers_sent_bytes.restype = ctypes.c_uint64
     lib.absent_peers_received_bytes.restype = ctypes.c_uint64
@@ -113,7 +119,7 @@ def main():
     ms = min(times) * 1e3
     flops = (32 if dt.is_complex else 8) * l ** 5 / G
     line = {"what": f"one rank's share of the l = {l} {a.dtype} transform sharded over {G} GPUs by leading-index rows, peers absent", "rank": r,
-            "world": G, "rows_in": il, "rows_out": jl, "ms_per_step": round(ms, 1), "rank_tflops": round(flops / ms / 1e9, 2),
+            "world": G, "link_gbs_per_peer_and_direction": a.link_gbs or None, "coalesced": a.coalesce, "rows_in": il, "rows_out": jl, "ms_per_step": round(ms, 1), "rank_tflops": round(flops / ms / 1e9, 2),
             "job_tflops_if_links_hidden": round(flops * G / ms / 1e9, 1), "peak_allocated_gib": round(peak / 2 ** 30, 1),
             "device_gib": round(total / 2 ** 30, 1), "free_after_gib": round(free1 / 2 ** 30, 1),
             "exchange_gb_per_step": {"sent": round(sent / 1e9, 2), "received": round(received / 1e9, 2)},
