@@ -41,12 +41,17 @@ def main():
     ap.add_argument("--dtype", default="c128")
     ap.add_argument("--chunk-rows", type=int, default=0)
     ap.add_argument("--samples", type=int, default=3)
+    ap.add_argument("--transport", default="", help="a prebuilt absent-peers stand-in (default: built into a temporary directory)")
+    ap.add_argument("--build-transport", default="", help="only build the stand-in to this path and exit")
     ap.add_argument("--coalesce", action="store_true", help="the exchange with one message per peer and step (qs_comm_set_option rows_coalesce)")
     ap.add_argument("--link-gbs", type=float, default=0.0,
                     help="model the link TIME: every exchange step holds the communicator's stream for (bytes of one peer) / this many GB/s")
     a = ap.parse_args()
     tmp = tempfile.mkdtemp(prefix="absent_peers_")
-    so = build_transport(tmp)
+    if a.build_transport:
+        shutil.copy(build_transport(tmp), a.build_transport)
+        return 0
+    so = a.transport or build_transport(tmp)
     os.environ["QS_AMD_RCCL_LIB"] = so
     if a.link_gbs > 0:
         os.environ["ABSENT_PEERS_LINK_GBS"] = str(a.link_gbs)
