@@ -12,6 +12,7 @@
 #include <stdint.h>
 #include <stdlib.h>
 #include <string.h>
+#include <unistd.h>
 
 #include <map>
 
@@ -41,7 +42,14 @@ int close_group() {
     for (auto& kv : g_in) if (kv.second > worst) worst = kv.second;
     g_out.clear(); g_in.clear();
     if (worst == 0 || link_bytes_per_tick() <= 0) return 0;
-    hipLaunchKernelGGL(link_time_kernel, dim3(1), dim3(64), 0, g_stream, (long long)(worst / link_bytes_per_tick()));
+    const long long ticks = (long long)(worst / link_bytes_per_tick());
+    // ABSENT_PEERS_HOST_DELAY: the stream is held by a host function that sleeps instead of a wave that spins -- the link time without
+    // ANY use of the GPU (a transfer engine); the default, one spinning wave, takes a wave slot and a few registers on one CU the way a
+    // (much larger) RCCL kernel does, which a product kernel that fills every CU to its register limit notices
+    static const bool host_delay = getenv("ABSENT_PEERS_HOST_DELAY") != nullptr;
+    if (host_delay)
+        return hipLaunchHostFunc(g_stream, [](void* t) { usleep((useconds_t)((long long)(intptr_t)t / 100)); }, (void*)(intptr_t)ticks) == hipSuccess ? 0 : 1;
+    hipLaunchKernelGGL(link_time_kernel, dim3(1), dim3(64), 0, g_stream, ticks);
     return hipGetLastError() == hipSuccess ? 0 : 1;
 }
 }  // namespace
