@@ -36,6 +36,13 @@ __global__ void link_time_kernel(long long ticks) {
     const long long t0 = wall_clock64();
     while (wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(32);
 }
+__global__ __launch_bounds__(512) void link_time_kernel_wide(long long ticks) {
+    __shared__ double pad[4096];      // 32 KB: what a channel's staging takes
+    pad[threadIdx.x] = 0.0;
+    const long long t0 = wall_clock64();
+    while (wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(32);
+    if (pad[threadIdx.x] != 0.0) __builtin_trap();
+}
 int close_group() {
     uint64_t worst = 0;
     for (auto& kv : g_out) if (kv.second > worst) worst = kv.second;
@@ -49,7 +56,11 @@ int close_group() {
     static const bool host_delay = getenv("ABSENT_PEERS_HOST_DELAY") != nullptr;
     if (host_delay)
         return hipLaunchHostFunc(g_stream, [](void* t) { usleep((useconds_t)((long long)(intptr_t)t / 100)); }, (void*)(intptr_t)ticks) == hipSuccess ? 0 : 1;
-    hipLaunchKernelGGL(link_time_kernel, dim3(1), dim3(64), 0, g_stream, ticks);
+    // ABSENT_PEERS_SPIN_WGS = n: the link time as n workgroups of 512 threads with 32 KB of LDS each -- the footprint of a communication
+    // kernel with n channels -- instead of one wave: does a product kernel that fills the chip lose more than the slots they take?
+    static const int wgs = [] { const char* e = getenv("ABSENT_PEERS_SPIN_WGS"); return e ? atoi(e) : 0; }();
+    if (wgs > 0) hipLaunchKernelGGL(link_time_kernel_wide, dim3(wgs), dim3(512), 0, g_stream, ticks);
+    else hipLaunchKernelGGL(link_time_kernel, dim3(1), dim3(64), 0, g_stream, ticks);
     return hipGetLastError() == hipSuccess ? 0 : 1;
 }
 }  // namespace
